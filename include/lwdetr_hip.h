@@ -1,0 +1,131 @@
+/* lwdetr_hip.h - C ABI of liblwdetr_hip.so (hand-written gfx950 kernels for the LW-DETR forward path).
+ *
+ * Conventions for every entry point:
+ *   - all tensor pointers are DEVICE pointers, borrowed for the duration of the call (no ownership transfer);
+ *   - outputs are caller-allocated and fully overwritten; nothing is allocated, nothing synchronises the host;
+ *   - work is enqueued on `hip_stream` (a hipStream_t passed as void*, NULL = default stream); stateless and
+ *     re-entrant per stream;
+ *   - return value: 0 on success, negative LWDETR_ERR_* otherwise (launch failures are reported from
+ *     hipGetLastError(), never just printed - the reference only printf's them, ms_deform_im2col_cuda.cuh:948-952);
+ *   - dtype codes: 0 = float32, 1 = float16, 2 = bfloat16 (3 = float64, deformable-attention op only).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   lwdetr_msda_forward        models/ops/src/ms_deform_attn.h:19-35 (ms_deform_attn_forward, pybind
+ *                              models/ops/src/vision.cpp:13-16) -> cuda/ms_deform_attn_cuda.cu:20-80 ->
+ *                              cuda/ms_deform_im2col_cuda.cuh:237-299
+ *   lwdetr_msda_fused_forward  models/ops/modules/ms_deform_attn.py:117-142 (softmax, location arithmetic, op call)
+ *   lwdetr_gemm                torch.nn.functional.linear / conv2d / conv_transpose2d call sites of
+ *                              models/backbone/vit.py:79-83,:123-138, timm Mlp, models/backbone/projector.py:85-132,
+ *                              :177-193, models/transformer.py:28-39,:231-240, models/attention.py:507-560,
+ *                              models/lwdetr.py:149-159 - with the bias / activation / LayerScale / residual /
+ *                              layout epilogues fused
+ *   lwdetr_attention           models/backbone/vit.py:130-137 (window and global softmax(QK^T)V) and
+ *                              models/attention.py:563-606 (decoder self-attention)
+ *   lwdetr_layernorm           nn.LayerNorm call sites (vit.py:199,:217; transformer.py:231,:499,:511,:516,:398) and
+ *                              the channel LayerNorm of models/backbone/projector.py:21-47
+ */
+#ifndef LWDETR_HIP_H
+#define LWDETR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LWDETR_OK 0
+#define LWDETR_ERR_BAD_ARG (-1)
+#define LWDETR_ERR_UNSUPPORTED (-2)
+#define LWDETR_ERR_LAUNCH (-3)
+
+/* out[b,q,m*D+c] = sum_l sum_p attn[b,q,m,l,p] * bilinear(value[b, lvl l, :, m, c], (loc_x*W_l-.5, loc_y*H_l-.5)), zero pad.
+ * value (B,S,M,D); shapes (L,2) int64 (H,W); level_start (L) int64; loc (B,Q,M,L,P,2) (x,y); attn (B,Q,M,L,P); out (B,Q,M*D). */
+int lwdetr_msda_forward(const void* value, const int64_t* shapes, const int64_t* level_start, const void* loc,
+                        const void* attn, void* out, int B, int S, int M, int D, int L, int Q, int P, int dtype,
+                        void* hip_stream);
+
+/* Model-path variant: oa is the (B*Q, ld_oa) output of the fused sampling_offsets|attention_weights Linear
+ * (offsets at column 0: M*L*P*2 values, logits at column logit_col: M*L*P values); ref_boxes (B,Q,4) f32 (cx,cy,w,h);
+ * valid_ratios (B,L,2) f32 (w,h). Computes softmax over L*P and loc = ref_xy + off / P * ref_wh * 0.5 in-kernel. D % 8 == 0. */
+int lwdetr_msda_fused_forward(const void* value, const int64_t* shapes, const int64_t* level_start, const void* oa,
+                              long ld_oa, int logit_col, const float* ref_boxes, const float* valid_ratios, void* out,
+                              int B, int S, int M, int D, int L, int Q, int P, int dtype, void* hip_stream);
+
+/* ---- fused MFMA GEMM: out = epilogue(A_view(M,K) * W(N,K)^T), see lwdetr_gemm_desc ---------------------------- */
+typedef struct {
+    int winmajor;      /* 0: rows are raster (b,y,x) tokens; 1: window-major padded rows (see DESIGN.md "data layout") */
+    int Hp, Wp, Twp;
+} lwdetr_tok_layout;
+
+enum { LWDETR_A_PLAIN = 0, LWDETR_A_CONV3x3 = 1, LWDETR_A_PATCH16 = 2 };
+enum { LWDETR_ACT_NONE = 0, LWDETR_ACT_RELU = 1, LWDETR_ACT_GELU = 2, LWDETR_ACT_SILU = 3 };
+enum { LWDETR_OUT_LINEAR = 0, LWDETR_OUT_HEADS = 1, LWDETR_OUT_HEADS_T = 2, LWDETR_OUT_TOKMAP = 3,
+       LWDETR_OUT_DECONV2x2 = 4 };
+
+typedef struct {           /* one column segment [n_begin, n_end) of the output */
+    void* out;             /* destination base */
+    void* out2;            /* optional second LINEAR destination (ViT feature taps), row stride ld2 */
+    const void* res;       /* optional residual, same dtype as out, addressed LINEAR with ldres; row = m % res_mod if res_mod>0 */
+    const float* bias;     /* optional (N) f32, indexed by n - n_begin + bias_off */
+    const float* gamma;    /* optional (N) f32 LayerScale: out = res + gamma * (acc + bias) */
+    const uint8_t* rowmask;/* optional (M): rows with mask == 0 contribute acc = 0 before bias */
+    float scale;           /* multiplies (acc + bias) */
+    int act;
+    int mode;              /* LWDETR_OUT_* */
+    int n_begin, n_end;
+    long ldo, ld2, ldres;
+    int res_mod;
+    int p0, p1, p2;        /* HEADS/HEADS_T: p0 = tokens per image Tp, p1 = head_dim, p2 = heads */
+    lwdetr_tok_layout in_tok, out_tok;   /* TOKMAP / DECONV2x2: row decode / encode layouts */
+    long out_batch_stride; /* TOKMAP / DECONV2x2: elements between images in out (0 = dense) */
+    long out_row_offset;   /* TOKMAP / DECONV2x2: first row inside an image (level offset into `memory`) */
+} lwdetr_gemm_seg;
+
+typedef struct {
+    const void* A; const void* A2;   /* A2 optional: A_view = A + A2 (same shape, PLAIN only) */
+    const void* W;                   /* (N, K) row-major, same dtype as A */
+    int M, N, K;
+    long lda;
+    int a_mode;
+    /* CONV3x3: A is (B, Hin, Win, ldc) tokens in layout a_tok with Cin channels at column a_col0; stride 1|2; K = 9*Cin.
+       PATCH16: A is the (B,3,H,W) image, rows are window-major tokens of a_tok; K = 768. */
+    lwdetr_tok_layout a_tok;
+    int conv_cin, conv_stride, a_col0, conv_hout, conv_wout;
+    int img_h, img_w;
+    int nseg;
+    lwdetr_gemm_seg seg[3];
+} lwdetr_gemm_desc;
+
+int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
+
+/* ---- fused softmax(QK^T)V, flash-style, MFMA ------------------------------------------------------------------- */
+typedef struct {
+    const void* Q;      /* (B, heads, Tp, hd)  pre-scaled by hd^-0.5 * log2(e) */
+    const void* K;      /* (B, heads, Tp, hd) */
+    const void* VT;     /* (B, heads, hd, Tp) */
+    void* out;          /* (B*Tp, ldo) row-major, head h writes columns [h*hd, (h+1)*hd) */
+    long ldo;
+    int B, heads, hd, Tp;
+    int seqs_per_img;   /* 16 (window attention) or 1 */
+    int seq_tok_stride; /* tokens between consecutive sequences of one image */
+    int keys_per_seq;   /* tokens (incl. pad rows) spanned by one sequence */
+    int sub_stride, sub_len; /* key j is real iff (j % sub_stride) < sub_len */
+    int kind;           /* 0 window, 1 global, 2 decoder self-attention (profiling label only) */
+} lwdetr_attn_desc;
+
+int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* hip_stream);
+
+/* ---- row LayerNorm: out[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta; biased variance; C % 4 == 0 ------------- */
+/* rows_per_batch / out_batch_stride / out_row_offset let the projector write straight into `memory` (B,S,d). */
+int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* out, long ldo, long M,
+                     int C, float eps, long rows_per_batch, long out_batch_rows, long out_row_offset, int dtype,
+                     void* hip_stream);
+
+/* ---- profiling: per-kernel HIP-event timing on the launch stream (off by default) ------------------------------ */
+int lwdetr_prof_enable(int on);
+int lwdetr_prof_num_kernels(void);
+const char* lwdetr_prof_kernel_name(int kid);
+int lwdetr_prof_collect(double* ms, double* flops, double* bytes, long long* count, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LWDETR_HIP_H */

@@ -1,0 +1,138 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of lwdetr_amd.
+// Wave = 64 lanes; MFMA fragments follow the 16x16 family layouts:
+//   A operand: lane l holds A[i = l & 15][k-run selected by g = l >> 4]
+//   B operand: lane l holds B[k-run selected by g][j = l & 15]
+//   C/D      : lane l holds D[i = 4 * g + r][j = l & 15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lwdetr_hip.h"   // public C ABI (include/), shared POD descriptors
+
+enum { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Vec;
+template <> struct Vec<float> { typedef f32x4 v4; typedef f32x8 v8; };
+template <> struct Vec<f16> { typedef f16x4 v4; typedef f16x8 v8; };
+template <> struct Vec<bf16> { typedef bf16x4 v4; typedef bf16x8 v8; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+// ---- MFMA wrappers: one call contracts 16 (k16) or 32 (k32) k-values held as 4 / 8 consecutive elements per lane.
+// For f32 the contraction is issued as 4 / 8 exact-f32 16x16x4 MFMAs (element s of every lane forms k-slice s;
+// the k order inside the chunk is a permutation shared by both operands, which leaves the product unchanged).
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+    static __device__ __forceinline__ f32x4 k32(f16x8 a, f16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(f16x4 a, f16x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ f32x4 k32(bf16x8 a, bf16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(bf16x4 a, bf16x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b),
+                                                         c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ f32x4 k32(f32x8 a, f32x8 b, f32x4 c) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ f32x4 k16(f32x4 a, f32x4 b, f32x4 c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T> __device__ __forceinline__ typename Vec<T>::v4 cvt4(f32x4 v) {
+    typename Vec<T>::v4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = from_f32<T>(v[i]);
+    return o;
+}
+template <typename T> __device__ __forceinline__ f32x4 up4(typename Vec<T>::v4 v) {
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = to_f32<T>(v[i]);
+    return o;
+}
+
+// ---- activations (match torch: exact-erf GELU, SiLU = x * sigmoid(x))
+enum { ACT_NONE = LWDETR_ACT_NONE, ACT_RELU = LWDETR_ACT_RELU, ACT_GELU = LWDETR_ACT_GELU, ACT_SILU = LWDETR_ACT_SILU };
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        case ACT_SILU: return x / (1.f + __expf(-x));
+        default: return x;
+    }
+}
+
+// ---- token layouts. A "row" m of an activation matrix addresses one token of one image.
+//  RASTER   : m = (b * Hp + y) * Wp + x
+//  WINMAJOR : m = b * Tp + win * Twp + i,  win = (y / h) * 4 + (x / w), i = (y % h) * w + (x % w), h = Hp/4, w = Wp/4,
+//             Twp = h*w rounded up to a multiple of 4 (pad rows i >= h*w carry no token), Tp = 16 * Twp.
+// The ViT keeps tokens window-major for its whole depth (reference: models/backbone/vit.py:353-358).
+typedef lwdetr_tok_layout TokLayout;   // {winmajor, Hp, Wp, Twp}
+struct TokPos { int b, y, x, valid; };
+
+__device__ __forceinline__ TokPos tok_decode(long m, const TokLayout& L) {
+    TokPos p;
+    if (!L.winmajor) {
+        const int hw = L.Hp * L.Wp;
+        p.b = (int)(m / hw);
+        const int r = (int)(m - (long)p.b * hw);
+        p.y = r / L.Wp; p.x = r - p.y * L.Wp; p.valid = 1;
+    } else {
+        const int Tp = 16 * L.Twp, h = L.Hp >> 2, w = L.Wp >> 2;
+        p.b = (int)(m / Tp);
+        const int r = (int)(m - (long)p.b * Tp);
+        const int win = r / L.Twp, i = r - win * L.Twp;
+        const int iy = i / w, ix = i - iy * w;
+        p.valid = i < h * w;
+        p.y = (win >> 2) * h + iy; p.x = (win & 3) * w + ix;
+    }
+    return p;
+}
+__device__ __forceinline__ long tok_encode(int b, int y, int x, const TokLayout& L) {
+    if (!L.winmajor) return ((long)b * L.Hp + y) * L.Wp + x;
+    const int h = L.Hp >> 2, w = L.Wp >> 2;
+    const int wy = y / h, wx = x / w;
+    return (long)b * 16 * L.Twp + (wy * 4 + wx) * L.Twp + (y - wy * h) * w + (x - wx * w);
+}
+
+// ---- profiling hooks (prof.hip): per-kernel HIP-event timing on the launch stream, off by default.
+enum {
+    KID_MSDA = 0, KID_MSDA_GENERIC, KID_MSDA_FUSED, KID_GEMM, KID_GEMM_CONV, KID_GEMM_PATCH, KID_ATTN_WINDOW,
+    KID_ATTN_GLOBAL, KID_ATTN_DECODER, KID_LAYERNORM, KID_ELTWISE, KID_COUNT
+};
+void lwdetr_prof_begin(int kid, double flops, double bytes, hipStream_t s);
+void lwdetr_prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s;
+    ProfScope(int kid, double flops, double bytes, hipStream_t st) : s(st) { lwdetr_prof_begin(kid, flops, bytes, st); }
+    ~ProfScope() { lwdetr_prof_end(s); }
+};
+
+static inline int lwdetr_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LWDETR_OK : LWDETR_ERR_LAUNCH;
+}

@@ -1,0 +1,331 @@
+// Fused MFMA GEMM for gfx950:  out = epilogue( A_view(M,K) x W(N,K)^T )
+//
+// One kernel family serves every dense contraction of the LW-DETR forward path (Linear, 1x1 / 3x3 / stride-2 conv,
+// 2x2 transposed conv, the 16x16 patch embedding) - the activations are token-major (NHWC) end to end, so all of them
+// are the same "rows x K" problem with a different A-row gather and a different epilogue:
+//   A views   : PLAIN (optionally A + A2), CONV3x3 (implicit GEMM, zero padded, stride 1|2, reads raster or window-major
+//               token layouts), PATCH16 (gathers 16x16x3 patches of the NCHW image, emits window-major token rows).
+//   epilogues : bias, ReLU / erf-GELU / SiLU, scale, LayerScale * x + residual, row masking, second destination (taps),
+//               and output layouts LINEAR, HEADS (B,heads,T,hd), HEADS_T (B,heads,hd,T), TOKMAP (row permutation between
+//               token layouts, e.g. window-major -> raster, or into a level slice of `memory`), DECONV2x2 (pixel shuffle).
+// Tiling: 256 threads = 4 waves (2 x 2), block tile BM x BN x 32, double-buffered LDS (one barrier per k-tile), global
+// loads of k-tile t+1 are in flight in registers while tile t feeds the MFMAs. Both operands are K-contiguous, so an
+// MFMA fragment is one 16-byte LDS read per lane.  Operand order of the MFMA is chosen per column segment so that each
+// lane ends up with 4 consecutive output elements along the destination's contiguous axis (8/16-byte stores):
+//   ROW  orientation: mfma(Wfrag, Xfrag) -> lane holds 4 consecutive n for one row m      (all modes but HEADS_T)
+//   COL  orientation: mfma(Xfrag, Wfrag) -> lane holds 4 consecutive m for one column n   (HEADS_T: V^T for attention)
+// Workgroup ids are remapped so that tiles sharing an A row-panel run on the same XCD (private L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+template <typename T, int BM, int BN, int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
+    constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+    constexpr int CPR = BK / EPC;              // chunks per tile row
+    constexpr int LDS_LD = BK + EPC;           // padded LDS row (elements)
+    constexpr int RPP = 256 / CPR;             // tile rows covered by one pass of the 256 threads
+    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+    constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
+    typedef typename Vec<T>::v8 V8;
+    typedef typename Vec<T>::v4 V4;
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LDS_LD];
+
+    // ---- XCD-aware, bijective workgroup remap (block b runs on XCD b % 8): consecutive logical tiles share an XCD
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lc = tid % CPR, lr = tid / CPR;
+
+    const T* __restrict__ A = (const T*)d.A;
+    const T* __restrict__ A2 = (const T*)d.A2;
+    const T* __restrict__ W = (const T*)d.W;
+
+    // ---- per-thread A row descriptors (fixed for the whole k loop)
+    const T* a_row[A_PASSES];
+    int a_b[A_PASSES], a_y[A_PASSES], a_x[A_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const long m = m0 + i * RPP + lr;
+        a_row[i] = nullptr; a_b[i] = -1; a_y[i] = 0; a_x[i] = 0;
+        if (m < d.M) {
+            if (AMODE == LWDETR_A_PLAIN) {
+                a_row[i] = A + m * d.lda;
+            } else if (AMODE == LWDETR_A_CONV3x3) {
+                const int hw = d.conv_hout * d.conv_wout;
+                const int b = (int)(m / hw), r = (int)(m - (long)b * hw);
+                a_b[i] = b; a_y[i] = r / d.conv_wout; a_x[i] = r - a_y[i] * d.conv_wout;
+            } else {
+                const TokPos p = tok_decode(m, d.a_tok);
+                if (p.valid) { a_b[i] = p.b; a_y[i] = p.y; a_x[i] = p.x; }
+            }
+        }
+    }
+    const T* w_row[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+        const int n = n0 + i * RPP + lr;
+        w_row[i] = n < d.N ? W + (long)n * d.K : nullptr;
+    }
+
+    uint4 ra[A_PASSES], rb[B_PASSES];
+
+    // Loads are unconditional from an always-valid address and masked afterwards: a `cond ? *p : 0` form makes the
+    // compiler select between p and a zero living in scratch (flat loads + private memory).
+    auto masked = [&](const uint4 v, bool ok) {
+        return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    };
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + lc * EPC;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const T* src = A;
+            bool ok = false;
+            if (AMODE == LWDETR_A_PLAIN) {
+                ok = a_row[i] != nullptr;
+                if (ok) src = a_row[i] + k;
+            } else if (AMODE == LWDETR_A_CONV3x3) {
+                const int tap = (kt * BK) / d.conv_cin;             // uniform: Cin % 32 == 0
+                const int ci = k - tap * d.conv_cin;
+                const int iy = a_y[i] * d.conv_stride + tap / 3 - 1, ix = a_x[i] * d.conv_stride + tap % 3 - 1;
+                ok = a_b[i] >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp;
+                if (ok) src = A + tok_encode(a_b[i], iy, ix, d.a_tok) * d.lda + d.a_col0 + ci;
+            } else {
+                ok = a_b[i] >= 0;
+                const int ch = k >> 8, py = (k >> 4) & 15, px = k & 15;
+                if (ok) src = A + (((long)a_b[i] * 3 + ch) * d.img_h + a_y[i] * 16 + py) * d.img_w + a_x[i] * 16 + px;
+            }
+            uint4 v = *(const uint4*)src;
+            if (AMODE == LWDETR_A_PLAIN && A2) {
+                typedef T VC __attribute__((ext_vector_type(EPC)));
+                VC va = __builtin_bit_cast(VC, v);
+                const VC vb = __builtin_bit_cast(VC, *(const uint4*)(A2 + (src - A)));
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) va[e] = from_f32<T>(to_f32<T>(va[e]) + to_f32<T>(vb[e]));
+                v = __builtin_bit_cast(uint4, va);
+            }
+            ra[i] = masked(v, ok);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const bool ok = w_row[i] != nullptr;
+            rb[i] = masked(*(const uint4*)((ok ? w_row[i] : W) + k), ok);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        T* As = smem + buf * (BM + BN) * LDS_LD;
+        T* Bs = As + BM * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) *(uint4*)(As + (i * RPP + lr) * LDS_LD + lc * EPC) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) *(uint4*)(Bs + (i * RPP + lr) * LDS_LD + lc * EPC) = rb[i];
+    };
+
+    // ---- segment of this column tile (segment boundaries are multiples of BN, checked by the launcher)
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 3; ++s) if (s < d.nseg && n0 >= d.seg[s].n_begin) si = s;
+    const lwdetr_gemm_seg& sg = d.seg[si];
+    const bool col_orient = sg.mode == LWDETR_OUT_HEADS_T;
+
+    f32x4 acc[FT][TT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = d.K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const T* As = smem + buf * (BM + BN) * LDS_LD;
+        const T* Bs = As + BM * LDS_LD;
+        V8 xf[TT], wf[FT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) xf[t] = *(const V8*)(As + (wm * WM + t * 16 + l15) * LDS_LD + g * 8);
+#pragma unroll
+        for (int f = 0; f < FT; ++f) wf[f] = *(const V8*)(Bs + (wn * WN + f * 16 + l15) * LDS_LD + g * 8);
+        if (!col_orient) {
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(wf[f], xf[t], acc[f][t]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(xf[t], wf[f], acc[f][t]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    T* __restrict__ out = (T*)sg.out;
+    T* __restrict__ out2 = (T*)sg.out2;
+    const T* __restrict__ res = (const T*)sg.res;
+    const int n_end = sg.n_end < d.N ? sg.n_end : d.N;
+    if (!col_orient) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const long m = m0 + wm * WM + t * 16 + l15;
+            if (m >= d.M) continue;
+            const bool keep = !sg.rowmask || sg.rowmask[m];
+            long rowoff = 0; bool row_ok = true;
+            int hb = 0, ht = 0; TokPos tp = {0, 0, 0, 1};
+            if (sg.mode == LWDETR_OUT_LINEAR) rowoff = m * sg.ldo;
+            else if (sg.mode == LWDETR_OUT_HEADS) { hb = (int)(m / sg.p0); ht = (int)(m - (long)hb * sg.p0); }
+            else {
+                tp = tok_decode(m, sg.in_tok); row_ok = tp.valid;
+                if (sg.mode == LWDETR_OUT_TOKMAP)
+                    rowoff = (long)tp.b * sg.out_batch_stride + (sg.out_row_offset + tok_encode(0, tp.y, tp.x, sg.out_tok)) * sg.ldo;
+            }
+            if (!row_ok) continue;
+            const long res_row = res ? (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres : 0;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                const int n = n0 + wn * WN + f * 16 + g * 4;
+                if (n >= n_end) continue;
+                const int nl = n - sg.n_begin;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = keep ? acc[f][t][r] : 0.f;
+                    const bool in = n + r < n_end;
+                    if (sg.bias && in) x += sg.bias[nl + r];
+                    x = apply_act(x, sg.act) * sg.scale;
+                    if (sg.gamma && in) x *= sg.gamma[nl + r];
+                    if (res && in) x += to_f32<T>(res[res_row + nl + r]);
+                    v[r] = x;
+                }
+                long off;
+                if (sg.mode == LWDETR_OUT_HEADS) {
+                    const int h = nl / sg.p1, dd = nl - h * sg.p1;
+                    off = (((long)hb * sg.p2 + h) * sg.p0 + ht) * sg.p1 + dd;
+                } else if (sg.mode == LWDETR_OUT_DECONV2x2) {
+                    const int q4 = nl / sg.p0, co = nl - q4 * sg.p0;
+                    off = (long)tp.b * sg.out_batch_stride +
+                          (sg.out_row_offset + tok_encode(0, 2 * tp.y + (q4 >> 1), 2 * tp.x + (q4 & 1), sg.out_tok)) * sg.ldo + co;
+                } else {
+                    off = rowoff + nl;
+                }
+                if (n + 3 < n_end && ((off & 3) == 0)) {
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+                    *(V4*)(out + off) = o;
+                    if (out2) *(V4*)(out2 + m * sg.ld2 + nl) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < n_end) {
+                        out[off + r] = from_f32<T>(v[r]);
+                        if (out2) out2[m * sg.ld2 + nl + r] = from_f32<T>(v[r]);
+                    }
+                }
+            }
+        }
+    } else {
+        // HEADS_T: lane holds rows m..m+3 (tokens) of column n: out[((b*heads+h)*hd+dd)*Tp + t .. t+3]
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const int n = n0 + wn * WN + f * 16 + l15;
+            if (n >= n_end) continue;
+            const int nl = n - sg.n_begin;
+            const float bias = sg.bias ? sg.bias[nl] : 0.f;
+            const int h = nl / sg.p1, dd = nl - h * sg.p1;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const long m = m0 + wm * WM + t * 16 + g * 4;
+                if (m >= d.M) continue;
+                const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
+                const long off = (((long)b * sg.p2 + h) * sg.p1 + dd) * sg.p0 + tk;
+                V4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act(acc[f][t][r] + bias, sg.act) * sg.scale);
+                if (m + 3 < d.M) *(V4*)(out + off) = o;
+                else for (int r = 0; r < 4; ++r) if (m + r < d.M) out[off + r] = o[r];
+            }
+        }
+    }
+}
+
+template <typename T, int AMODE>
+int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
+    // column tile: 128 unless a segment boundary (or a small N) asks for 64
+    bool bn64 = d.N <= 64 || sizeof(T) == 4;   // f32 (parity mode) tiles are 128 x 64 to stay inside 64 KB of LDS
+    for (int s = 0; s < d.nseg; ++s)
+        if ((d.seg[s].n_begin % 128) != 0) bn64 = true;
+    const int BNsel = bn64 ? 64 : 128;
+    for (int s = 0; s < d.nseg; ++s)
+        if (d.seg[s].n_begin % BNsel != 0) return LWDETR_ERR_UNSUPPORTED;
+    const long tiles_m = (d.M + 127) / 128, tiles_n = (d.N + BNsel - 1) / BNsel;
+    const long nwg = tiles_m * tiles_n;
+    if (nwg <= 0 || nwg > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
+    const int kid = AMODE == LWDETR_A_PLAIN ? KID_GEMM : (AMODE == LWDETR_A_CONV3x3 ? KID_GEMM_CONV : KID_GEMM_PATCH);
+    ProfScope ps(kid, 2.0 * d.M * d.N * d.K, ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) * sizeof(T), st);
+    if (bn64) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+    else if constexpr (sizeof(T) == 2)
+        hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+    return lwdetr_check_launch();
+}
+
+template <typename T>
+int dispatch_amode(const lwdetr_gemm_desc& d, hipStream_t st) {
+    switch (d.a_mode) {
+        case LWDETR_A_PLAIN: return launch<T, LWDETR_A_PLAIN>(d, st);
+        case LWDETR_A_CONV3x3: return launch<T, LWDETR_A_CONV3x3>(d, st);
+        case LWDETR_A_PATCH16: return launch<T, LWDETR_A_PATCH16>(d, st);
+        default: return LWDETR_ERR_BAD_ARG;
+    }
+}
+
+}  // namespace
+
+extern "C" int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream) {
+    if (!desc) return LWDETR_ERR_BAD_ARG;
+    const lwdetr_gemm_desc& d = *desc;
+    if (d.M < 0 || d.N <= 0 || d.K <= 0 || d.K % BK != 0 || !d.A || !d.W) return LWDETR_ERR_BAD_ARG;
+    if (d.M == 0) return LWDETR_OK;
+    if (d.nseg < 1 || d.nseg > 3 || d.seg[0].n_begin != 0) return LWDETR_ERR_BAD_ARG;
+    const int esz = dtype == DT_F32 ? 4 : 2;
+    const int epc = 16 / esz;
+    for (int s = 0; s < d.nseg; ++s) {
+        const lwdetr_gemm_seg& g = d.seg[s];
+        if (!g.out || g.n_end <= g.n_begin) return LWDETR_ERR_BAD_ARG;
+        if (s + 1 < d.nseg && d.seg[s + 1].n_begin != g.n_end) return LWDETR_ERR_BAD_ARG;
+        if ((g.mode == LWDETR_OUT_HEADS || g.mode == LWDETR_OUT_HEADS_T) &&
+            (g.p0 <= 0 || g.p1 <= 0 || g.p2 <= 0 || g.p1 % 4 != 0 || g.p0 % 4 != 0)) return LWDETR_ERR_BAD_ARG;
+        if (g.mode == LWDETR_OUT_DECONV2x2 && (g.p0 <= 0 || g.p0 % 4 != 0)) return LWDETR_ERR_BAD_ARG;
+        if (g.mode < 0 || g.mode > LWDETR_OUT_DECONV2x2) return LWDETR_ERR_BAD_ARG;
+    }
+    if (d.seg[d.nseg - 1].n_end < d.N) return LWDETR_ERR_BAD_ARG;
+    if (d.a_mode == LWDETR_A_PLAIN && (d.lda % epc != 0)) return LWDETR_ERR_BAD_ARG;
+    if (d.a_mode == LWDETR_A_CONV3x3 &&
+        (d.conv_cin % BK != 0 || d.K != 9 * d.conv_cin || (d.conv_stride != 1 && d.conv_stride != 2) ||
+         d.lda % epc != 0 || d.a_col0 % epc != 0 || d.conv_hout <= 0 || d.conv_wout <= 0)) return LWDETR_ERR_BAD_ARG;
+    if (d.a_mode == LWDETR_A_PATCH16 && (d.K != 768 || d.img_w % 16 != 0 || d.img_h % 16 != 0)) return LWDETR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (dtype) {
+        case DT_F32: return dispatch_amode<float>(d, st);
+        case DT_F16: return dispatch_amode<f16>(d, st);
+        case DT_BF16: return dispatch_amode<bf16>(d, st);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}

@@ -1,0 +1,66 @@
+// Per-kernel launch timing with HIP events recorded on the stream each kernel is launched on.
+// Off by default (zero overhead besides one branch); bench.py switches it on for a dedicated
+// measurement pass so that roofline.achieved comes from the kernel's own launch durations.
+#include "common.h"
+#include <mutex>
+#include <vector>
+
+namespace {
+struct Rec { hipEvent_t a, b; int kid; double flops, bytes; };
+std::mutex g_mu;
+std::vector<Rec> g_open;       // begun, not yet ended (per stream nesting is not used)
+std::vector<Rec> g_done;
+bool g_on = false;
+const char* kNames[KID_COUNT] = {
+    "msda_forward_vec8", "msda_forward_generic", "msda_fused_forward", "gemm_mfma", "gemm_mfma_conv3x3",
+    "gemm_mfma_patch", "attn_window", "attn_global", "attn_decoder", "layernorm_rows", "eltwise"};
+}  // namespace
+
+void lwdetr_prof_begin(int kid, double flops, double bytes, hipStream_t s) {
+    if (!g_on) return;
+    Rec r; r.kid = kid; r.flops = flops; r.bytes = bytes;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_open.push_back(r);
+}
+
+void lwdetr_prof_end(hipStream_t s) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_open.empty()) return;
+    Rec r = g_open.back();
+    g_open.pop_back();
+    (void)hipEventRecord(r.b, s);
+    g_done.push_back(r);
+}
+
+extern "C" {
+
+int lwdetr_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return LWDETR_OK;
+}
+
+int lwdetr_prof_num_kernels() { return KID_COUNT; }
+
+const char* lwdetr_prof_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? kNames[kid] : ""; }
+
+// Synchronises all recorded events, accumulates per kernel id and clears the log.
+// ms / flops / bytes / count are caller arrays of n >= lwdetr_prof_num_kernels() entries (accumulated into).
+int lwdetr_prof_collect(double* ms, double* flops, double* bytes, long long* count, int n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (n < KID_COUNT) return LWDETR_ERR_BAD_ARG;
+    for (Rec& r : g_done) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms[r.kid] += t; flops[r.kid] += r.flops; bytes[r.kid] += r.bytes; count[r.kid] += 1;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_done.clear();
+    return LWDETR_OK;
+}
+
+}  // extern "C"

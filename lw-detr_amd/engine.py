@@ -1,0 +1,483 @@
+"""Launch-plan engine: turns an LW-DETR state dict into packed device weights and a flat list of pre-built kernel
+launches (C ABI of ``liblwdetr_hip.so``) for one (batch, resolution, dtype).
+
+Data layout (all activations are token-major / NHWC, dtype T = model dtype):
+  * ViT stream  x[B*Tp, C]: tokens in the reference's window-major order (``models/backbone/vit.py:353-358``), every
+    window padded to Twp = ceil4(h*w) rows so that all 8/16-byte vector accesses stay aligned (Tp = 16*Twp; no padding
+    at 640x640 where h*w = 100). Window attention = 16 contiguous sequences per image, global attention = one.
+  * Q, K (B, heads, Tp, hd), V^T (B, heads, hd, Tp): written directly by the QKV GEMM epilogue.
+  * projector / memory: raster NHWC; ``memory`` is (B, S, d) with the levels concatenated - the projector's final
+    LayerNorm writes straight into its level slice, so there is no flatten/transpose/cat (``transformer.py:199-222``).
+Dead compute of the reference that is not executed (results unused): sine position embedding of
+memory, head-averaged self-attention weights, per-call bicubic pos-embed resize (cached per resolution).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+from .kernels import (A_CONV3x3, A_PATCH16, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, OUT_DECONV2x2, OUT_HEADS,
+                      OUT_HEADS_T, OUT_LINEAR, OUT_TOKMAP, AttnOp, GemmOp, LayerNormOp, MsdaFusedOp, seg, tok_layout)
+from .models.modules import LEVEL_SCALE, VIT_SIZES
+
+
+def _ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+class PackedWeights:
+    """Device-resident, kernel-ready copies of the parameters (weights in T, biases / scales in f32)."""
+
+    def __init__(self, sd, cfg, device, dtype):
+        self.device, self.dtype, self.cfg = device, dtype, cfg
+        self.sd = sd
+        self._cache = {}
+
+    def w(self, key, fn=None, tag=""):
+        """Weight matrix in T (optionally transformed by ``fn`` on the f32 master copy)."""
+        ck = ("w", key, tag)
+        if ck not in self._cache:
+            t = self.sd[key].detach().float()
+            if fn is not None:
+                t = fn(t)
+            self._cache[ck] = t.to(device=self.device, dtype=self.dtype).contiguous()
+        return self._cache[ck]
+
+    def f(self, key, fn=None, tag=""):
+        """f32 vector (bias / LayerScale / norm parameters)."""
+        ck = ("f", key, tag)
+        if ck not in self._cache:
+            t = self.sd[key].detach().float()
+            if fn is not None:
+                t = fn(t)
+            self._cache[ck] = t.to(device=self.device, dtype=torch.float32).contiguous()
+        return self._cache[ck]
+
+    def custom(self, name, builder, dtype=None):
+        ck = ("c", name)
+        if ck not in self._cache:
+            self._cache[ck] = builder().to(device=self.device, dtype=dtype or self.dtype).contiguous()
+        return self._cache[ck]
+
+    # ---- conv + eval-BatchNorm folding (reference ConvX: conv(bias=False) -> BN -> act, projector.py:85-98)
+    def convx(self, prefix):
+        ck = ("convx", prefix)
+        if ck not in self._cache:
+            w = self.sd[prefix + ".conv.weight"].detach().float()
+            g = self.sd[prefix + ".bn.weight"].detach().float()
+            b = self.sd[prefix + ".bn.bias"].detach().float()
+            mu = self.sd[prefix + ".bn.running_mean"].detach().float()
+            var = self.sd[prefix + ".bn.running_var"].detach().float()
+            s = g / torch.sqrt(var + 1e-5)
+            w = w * s[:, None, None, None]
+            wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)         # (Cout, ky*kx*Cin): k = tap*Cin + ci
+            self._cache[ck] = (wk.to(device=self.device, dtype=self.dtype).contiguous(),
+                               (b - mu * s).to(device=self.device, dtype=torch.float32).contiguous())
+        return self._cache[ck]
+
+
+def abs_pos_winmajor(pos_embed, hp, wp, twp):
+    """pos_embed (1, 1+14*14, C) -> (16*twp, C) f32: cls token dropped, bicubic resize (align_corners=False),
+    window-major order, zero pad rows. Reference: models/backbone/vit.py:26-54, :353-358."""
+    p = pos_embed[:, 1:].float()
+    s = int(math.isqrt(p.shape[1]))
+    c = p.shape[-1]
+    if (s, s) != (hp, wp):
+        p = F.interpolate(p.reshape(1, s, s, c).permute(0, 3, 1, 2), size=(hp, wp), mode="bicubic",
+                          align_corners=False).permute(0, 2, 3, 1)
+    else:
+        p = p.reshape(1, hp, wp, c)
+    h, w = hp // 4, wp // 4
+    p = p.reshape(4, h, 4, w, c).permute(0, 2, 1, 3, 4).reshape(16, h * w, c)
+    out = torch.zeros(16, twp, c, dtype=torch.float32, device=p.device)
+    out[:, :h * w] = p
+    return out.reshape(16 * twp, c)
+
+
+def sine_embed(pos, dim):
+    """(B, nq, 4) -> (B, nq, 4*dim) in order (y, x, w, h). Reference: models/transformer.py:42-68."""
+    dim_t = torch.arange(dim, dtype=torch.float32, device=pos.device)
+    dim_t = 10000 ** (2 * (dim_t // 2) / dim)
+    out = []
+    for idx in (1, 0, 2, 3):
+        e = pos[:, :, idx, None] * (2 * math.pi) / dim_t
+        out.append(torch.stack((e[:, :, 0::2].sin(), e[:, :, 1::2].cos()), dim=3).flatten(2))
+    return torch.cat(out, dim=2)
+
+
+def reparam(delta, ref):
+    """Box re-parameterisation, no sigmoid (reference models/transformer.py:236-240, models/lwdetr.py:150-155)."""
+    return torch.cat([delta[..., :2] * ref[..., 2:] + ref[..., :2], delta[..., 2:].exp() * ref[..., 2:]], -1)
+
+
+class ForwardPlan:
+    """All launches of one inference forward for fixed (B, H, W, dtype); buffers are allocated once."""
+
+    def __init__(self, pw: PackedWeights, batch, height, width):
+        cfg = pw.cfg
+        self.pw, self.cfg = pw, cfg
+        self.B, self.H, self.W = batch, height, width
+        dev, T = pw.device, pw.dtype
+        self.dev, self.T = dev, T
+        if height % 64 or width % 64:
+            raise AssertionError("image height and width must be multiples of 64 (vit.py:354)")
+        C, heads = VIT_SIZES[cfg.encoder]
+        self.C, self.heads, self.hd = C, heads, C // heads
+        self.Hp, self.Wp = height // 16, width // 16
+        h, w = self.Hp // 4, self.Wp // 4
+        self.Tw, self.Twp = h * w, _ceil4(h * w)
+        self.Tp = 16 * self.Twp
+        self.rows = batch * self.Tp
+        self.depth = cfg.vit_encoder_num_layers
+        self.taps = sorted(i if i >= 0 else i + self.depth for i in cfg.out_feature_indexes)
+        self.d = cfg.hidden_dim
+        self.nq = cfg.num_queries
+        self.L = len(cfg.projector_scale)
+        self.level_hw = [(int(self.Hp * LEVEL_SCALE[s]), int(self.Wp * LEVEL_SCALE[s])) for s in cfg.projector_scale]
+        self.lsi = [0]
+        for (a, b) in self.level_hw[:-1]:
+            self.lsi.append(self.lsi[-1] + a * b)
+        self.S = sum(a * b for a, b in self.level_hw)
+        if self.S < self.nq:
+            raise RuntimeError(f"image too small: {self.S} memory tokens < {self.nq} queries")
+        self.win_tok = tok_layout(True, self.Hp, self.Wp, self.Twp)
+        self.ops_backbone, self.ops_enc, self.ops_sel, self.ops_dec = [], [], [], []
+        self.debug = {}
+        self._z = lambda *s, dt=None: torch.zeros(*s, dtype=dt or T, device=dev)
+        self._build_vit()
+        self._build_projector()
+        self._build_transformer()
+
+    # ------------------------------------------------------------------------------------------------ ViT
+    def _build_vit(self):
+        pw, C, B, Tp, rows, heads, hd = self.pw, self.C, self.B, self.Tp, self.rows, self.heads, self.hd
+        z, ops = self._z, self.ops_backbone
+        pre = "backbone.0.encoder"
+        self.images = z(B, 3, self.H, self.W)
+        self.x = z(rows, C)
+        xn, att, hid = z(rows, C), z(rows, C), z(rows, 4 * C)
+        q, k, vt = z(B, heads, Tp, hd), z(B, heads, Tp, hd), z(B, heads, hd, Tp)
+        ntap = len(self.taps)
+        self.taps_cat = z(rows, ntap * C)
+        pos = pw.custom(f"pos.{self.Hp}x{self.Wp}", lambda: abs_pos_winmajor(pw.sd[pre + ".pos_embed"].detach().cpu(),
+                                                                           self.Hp, self.Wp, self.Twp))
+        wpe = pw.w(pre + ".patch_embed.proj.weight", lambda t: t.reshape(t.shape[0], -1))
+        ops.append(GemmOp(self.images, wpe, rows, C, 768, [
+            seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp)],
+            a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
+        qscale = K.attention_scale(hd)
+        for i in range(self.depth):
+            blk = f"{pre}.blocks.{i}"
+            window = i in self.cfg.window_block_indexes
+            ops.append(LayerNormOp(self.x, pw.f(blk + ".norm1.weight"), pw.f(blk + ".norm1.bias"), xn, rows, C, 1e-6))
+            ops.append(GemmOp(xn, pw.w(blk + ".attn.qkv.weight"), rows, 3 * C, C, [
+                seg(q, 0, C, mode=OUT_HEADS, bias=pw.f(blk + ".attn.q_bias"), scale=qscale, p0=Tp, p1=hd, p2=heads),
+                seg(k, C, 2 * C, mode=OUT_HEADS, p0=Tp, p1=hd, p2=heads),
+                seg(vt, 2 * C, 3 * C, mode=OUT_HEADS_T, bias=pw.f(blk + ".attn.v_bias"), p0=Tp, p1=hd, p2=heads)]))
+            if window:
+                ops.append(AttnOp(q, k, vt, att, B=B, heads=heads, hd=hd, Tp=Tp, ldo=C, seqs_per_img=16,
+                                  seq_tok_stride=self.Twp, keys_per_seq=self.Twp, sub_stride=self.Twp,
+                                  sub_len=self.Tw, kind=0))
+            else:
+                ops.append(AttnOp(q, k, vt, att, B=B, heads=heads, hd=hd, Tp=Tp, ldo=C, seqs_per_img=1,
+                                  seq_tok_stride=Tp, keys_per_seq=Tp, sub_stride=self.Twp, sub_len=self.Tw, kind=1))
+            ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
+                seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
+                    res=self.x, ldres=C)]))
+            ops.append(LayerNormOp(self.x, pw.f(blk + ".norm2.weight"), pw.f(blk + ".norm2.bias"), xn, rows, C, 1e-6))
+            ops.append(GemmOp(xn, pw.w(blk + ".mlp.fc1.weight"), rows, 4 * C, C, [
+                seg(hid, 0, 4 * C, ldo=4 * C, bias=pw.f(blk + ".mlp.fc1.bias"), act=ACT_GELU)]))
+            tap_out = None
+            if i in self.taps:
+                j = self.taps.index(i)
+                tap_out = self.taps_cat[:, j * C:]
+            ops.append(GemmOp(hid, pw.w(blk + ".mlp.fc2.weight"), rows, C, 4 * C, [
+                seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".mlp.fc2.bias"), gamma=pw.f(blk + ".gamma_2"), res=self.x,
+                    ldres=C, out2=tap_out, ld2=ntap * C)], keep=(tap_out,)))
+
+    # ------------------------------------------------------------------------------------------ projector
+    def _convx_1x1(self, prefix, A, lda, M, cin, out_seg_fn, a_ptr_off=0):
+        w, b = self.pw.convx(prefix)
+        act = ACT_SILU if ".stages." in prefix else ACT_RELU
+        return GemmOp(A, w, M, w.shape[0], cin, [out_seg_fn(b, act, w.shape[0])], lda=lda, keep=(w, b))
+
+    def _build_projector(self):
+        pw, cfg, C, B, d = self.pw, self.cfg, self.C, self.B, self.d
+        z, ops = self._z, self.ops_backbone
+        ntap = len(self.taps)
+        pre = "backbone.0.projector"
+        self.memory = z(B * self.S, d)
+        self.level_feats = []
+        for li, name in enumerate(cfg.projector_scale):
+            scale = LEVEL_SCALE[name]
+            hl, wl = self.level_hw[li]
+            npix = hl * wl
+            M = B * npix
+            ras = tok_layout(False, hl, wl, 0)
+            st = f"{pre}.stages.{li}.0"
+            c = d // 2
+            ycat = z(M, 5 * c)
+            w1, b1 = pw.convx(st + ".cv1")
+            if scale == 1.0:
+                # C2f.cv1 consumes the window-major tap concat and un-windows in its epilogue
+                ops.append(GemmOp(self.taps_cat, w1, self.rows, 2 * c, ntap * C, [
+                    seg(ycat, 0, 2 * c, mode=OUT_TOKMAP, ldo=5 * c, bias=b1, act=ACT_SILU, in_tok=self.win_tok,
+                        out_tok=ras, out_batch_stride=npix * 5 * c)]))
+            else:
+                if scale == 2.0:
+                    c_out = C // 4 if C > 512 else C // 2
+                    cat = z(M, ntap * c_out)
+                    for j in range(ntap):
+                        sp = f"{pre}.stages_sampling.{li}.{j}"
+                        src, lda, kin = self.taps_cat[:, j * C:], ntap * C, C
+                        di = 0
+                        if C > 512:
+                            wx, bx = pw.convx(sp + ".0")
+                            tmp = z(self.rows, C // 2)
+                            ops.append(GemmOp(src, wx, self.rows, C // 2, C, [
+                                seg(tmp, 0, C // 2, ldo=C // 2, bias=bx, act=ACT_RELU)], lda=lda, keep=(src,)))
+                            src, lda, kin, di = tmp, C // 2, C // 2, 1
+                        wd = pw.w(f"{sp}.{di}.weight", lambda t: t.permute(2, 3, 1, 0).reshape(-1, t.shape[0]))
+                        bd = pw.f(f"{sp}.{di}.bias", lambda t: t.repeat(4))
+                        dst = cat[:, j * c_out:]
+                        ops.append(GemmOp(src, wd, self.rows, 4 * c_out, kin, [
+                            seg(dst, 0, 4 * c_out, mode=OUT_DECONV2x2, ldo=ntap * c_out, bias=bd, p0=c_out,
+                                in_tok=self.win_tok, out_tok=ras, out_batch_stride=npix * ntap * c_out)],
+                            lda=lda, keep=(src, dst)))
+                    kcat = ntap * c_out
+                else:   # 0.5: ConvX(C, C, 3, stride 2), ReLU
+                    cat = z(M, ntap * C)
+                    for j in range(ntap):
+                        wx, bx = pw.convx(f"{pre}.stages_sampling.{li}.{j}.0")
+                        dst = cat[:, j * C:]
+                        ops.append(GemmOp(self.taps_cat, wx, M, C, 9 * C, [
+                            seg(dst, 0, C, ldo=ntap * C, bias=bx, act=ACT_RELU)], lda=ntap * C, a_mode=A_CONV3x3,
+                            a_tok=self.win_tok, conv_cin=C, conv_stride=2, a_col0=j * C, conv_hout=hl, conv_wout=wl,
+                            keep=(dst,)))
+                    kcat = ntap * C
+                ops.append(GemmOp(cat, w1, M, 2 * c, kcat, [seg(ycat, 0, 2 * c, ldo=5 * c, bias=b1, act=ACT_SILU)]))
+            tmp = z(M, c)
+            for m in range(3):
+                wa, ba = pw.convx(f"{st}.m.{m}.cv1")
+                wb, bb = pw.convx(f"{st}.m.{m}.cv2")
+                dst = ycat[:, (2 + m) * c:]
+                ops.append(GemmOp(ycat, wa, M, c, 9 * c, [seg(tmp, 0, c, ldo=c, bias=ba, act=ACT_SILU)], lda=5 * c,
+                                  a_mode=A_CONV3x3, a_tok=ras, conv_cin=c, conv_stride=1, a_col0=(1 + m) * c,
+                                  conv_hout=hl, conv_wout=wl))
+                ops.append(GemmOp(tmp, wb, M, c, 9 * c, [seg(dst, 0, c, ldo=5 * c, bias=bb, act=ACT_SILU)], lda=c,
+                                  a_mode=A_CONV3x3, a_tok=ras, conv_cin=c, conv_stride=1, a_col0=0, conv_hout=hl,
+                                  conv_wout=wl, keep=(dst,)))
+            w2, b2 = pw.convx(st + ".cv2")
+            zf = z(M, d)
+            ops.append(GemmOp(ycat, w2, M, d, 5 * c, [seg(zf, 0, d, ldo=d, bias=b2, act=ACT_SILU)]))
+            ops.append(LayerNormOp(zf, pw.f(f"{pre}.stages.{li}.1.weight"), pw.f(f"{pre}.stages.{li}.1.bias"),
+                                   self.memory, M, d, 1e-6, rows_per_batch=npix, out_batch_rows=self.S,
+                                   out_row_offset=self.lsi[li]))
+
+    # ---------------------------------------------------------------------------------------- transformer
+    def _build_transformer(self):
+        pw, cfg, B, d, S, nq, L = self.pw, self.cfg, self.B, self.d, self.S, self.nq, self.L
+        z = self._z
+        t = "transformer"
+        dev = self.dev
+        self.shapes_t = torch.tensor(self.level_hw, dtype=torch.int64, device=dev)
+        self.lsi_t = torch.tensor(self.lsi, dtype=torch.int64, device=dev)
+        # ---- encoder-side (all S tokens): enc_output Linear+LN, class logits; value_proj of all decoder layers
+        self.rowvalid = torch.ones(B * S, dtype=torch.uint8, device=dev)
+        self.notpad = torch.ones(B * S, dtype=torch.uint8, device=dev)
+        e1, self.om = z(B * S, d), z(B * S, d)
+        self.ncls = pw.sd["class_embed.weight"].shape[0]
+        self.ldc = _ceil4(self.ncls)
+        self.enc_cls = z(B * S, self.ldc)
+        ops = self.ops_enc
+        ops.append(GemmOp(self.memory, pw.w(f"{t}.enc_output.0.weight"), B * S, d, d, [
+            seg(e1, 0, d, ldo=d, bias=pw.f(f"{t}.enc_output.0.bias"), rowmask=self.rowvalid)]))
+        ops.append(LayerNormOp(e1, pw.f(f"{t}.enc_output_norm.0.weight"), pw.f(f"{t}.enc_output_norm.0.bias"),
+                               self.om, B * S, d, 1e-5))
+        ops.append(GemmOp(self.om, pw.w(f"{t}.enc_out_class_embed.0.weight"), B * S, self.ncls, d, [
+            seg(self.enc_cls, 0, self.ncls, ldo=self.ldc, bias=pw.f(f"{t}.enc_out_class_embed.0.bias"))]))
+        nl = cfg.dec_layers
+        wv = pw.custom("value_proj_all.w", lambda: torch.cat(
+            [pw.sd[f"{t}.decoder.layers.{i}.cross_attn.value_proj.weight"].detach().float() for i in range(nl)], 0))
+        bv = pw.custom("value_proj_all.b", lambda: torch.cat(
+            [pw.sd[f"{t}.decoder.layers.{i}.cross_attn.value_proj.bias"].detach().float() for i in range(nl)], 0),
+            dtype=torch.float32)
+        self.values = [z(B * S, d) for _ in range(nl)]
+        vsegs = [seg(self.values[i], i * d, (i + 1) * d, ldo=d, bias=bv[i * d:], rowmask=self.notpad)
+                 for i in range(nl)]
+        for g0 in range(0, nl, 3):
+            grp = vsegs[g0:g0 + 3]
+            for s_ in grp:
+                s_.n_begin -= g0 * d
+                s_.n_end -= g0 * d
+            ops.append(GemmOp(self.memory, wv[g0 * d:], B * S, len(grp) * d, d, grp, keep=(wv, bv)))
+        # ---- selected queries: bbox MLP of the two-stage head on the nq gathered rows only (row-wise op)
+        self.om_sel = z(B * nq, d)
+        s1, s2 = z(B * nq, d), z(B * nq, d)
+        self.enc_delta = z(B * nq, 4)
+        ops = self.ops_sel
+        be = f"{t}.enc_out_bbox_embed.0.layers"
+        ops.append(GemmOp(self.om_sel, pw.w(be + ".0.weight"), B * nq, d, d, [seg(s1, 0, d, ldo=d, bias=pw.f(be + ".0.bias"), act=ACT_RELU)]))
+        ops.append(GemmOp(s1, pw.w(be + ".1.weight"), B * nq, d, d, [seg(s2, 0, d, ldo=d, bias=pw.f(be + ".1.bias"), act=ACT_RELU)]))
+        ops.append(GemmOp(s2, pw.w(be + ".2.weight"), B * nq, 4, d, [seg(self.enc_delta, 0, 4, ldo=4, bias=pw.f(be + ".2.bias"))]))
+        # ---- decoder
+        ops = self.ops_dec
+        M, D = cfg.ca_nheads, d // cfg.ca_nheads
+        P = cfg.dec_n_points
+        sa_h, sa_hd = cfg.sa_nheads, d // cfg.sa_nheads
+        rq = B * nq
+        self.xdec = z(rq, d)
+        self.sine = z(rq, 2 * d)
+        self.qpos = z(rq, d)
+        self.ref = torch.zeros(B, nq, 4, dtype=torch.float32, device=dev)
+        self.vr = torch.ones(B, L, 2, dtype=torch.float32, device=dev)
+        self.hs = z(nl, rq, d)
+        r1 = z(rq, d)
+        rp = f"{t}.decoder.ref_point_head.layers"
+        ops.append(GemmOp(self.sine, pw.w(rp + ".0.weight"), rq, d, 2 * d, [seg(r1, 0, d, ldo=d, bias=pw.f(rp + ".0.bias"), act=ACT_RELU)]))
+        ops.append(GemmOp(r1, pw.w(rp + ".1.weight"), rq, d, d, [seg(self.qpos, 0, d, ldo=d, bias=pw.f(rp + ".1.bias"))]))
+        qd, kd, vtd = z(B, sa_h, nq, sa_hd), z(B, sa_h, nq, sa_hd), z(B, sa_h, sa_hd, nq)
+        attd, y, ca, ffn = z(rq, d), z(rq, d), z(rq, d), z(rq, cfg.dim_feedforward)
+        lp3 = M * L * P * 3
+        ld_oa = _ceil4(lp3)
+        oa = z(rq, ld_oa)
+        for li in range(nl):
+            lay = f"{t}.decoder.layers.{li}"
+            ipw, ipb = lay + ".self_attn.in_proj_weight", lay + ".self_attn.in_proj_bias"
+            ops.append(GemmOp(self.xdec, pw.w(ipw, lambda w_: w_[:2 * d], "qk"), rq, 2 * d, d, [
+                seg(qd, 0, d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[:d], "q"), scale=K.attention_scale(sa_hd),
+                    p0=nq, p1=sa_hd, p2=sa_h),
+                seg(kd, d, 2 * d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[d:2 * d], "k"), p0=nq, p1=sa_hd, p2=sa_h)],
+                A2=self.qpos))
+            ops.append(GemmOp(self.xdec, pw.w(ipw, lambda w_: w_[2 * d:], "v"), rq, d, d, [
+                seg(vtd, 0, d, mode=OUT_HEADS_T, bias=pw.f(ipb, lambda b_: b_[2 * d:], "v"), p0=nq, p1=sa_hd, p2=sa_h)]))
+            ops.append(AttnOp(qd, kd, vtd, attd, B=B, heads=sa_h, hd=sa_hd, Tp=nq, ldo=d, seqs_per_img=1,
+                              seq_tok_stride=nq, keys_per_seq=nq, sub_stride=nq, sub_len=nq, kind=2))
+            ops.append(GemmOp(attd, pw.w(lay + ".self_attn.out_proj.weight"), rq, d, d, [
+                seg(y, 0, d, ldo=d, bias=pw.f(lay + ".self_attn.out_proj.bias"), res=self.xdec, ldres=d)]))
+            ops.append(LayerNormOp(y, pw.f(lay + ".norm1.weight"), pw.f(lay + ".norm1.bias"), self.xdec, rq, d, 1e-5))
+            ca_p = lay + ".cross_attn"
+            w_oa = pw.custom(ca_p + ".oa.w", lambda ca_p=ca_p: torch.cat(
+                [pw.sd[ca_p + ".sampling_offsets.weight"].detach().float(),
+                 pw.sd[ca_p + ".attention_weights.weight"].detach().float()], 0))
+            b_oa = pw.custom(ca_p + ".oa.b", lambda ca_p=ca_p: torch.cat(
+                [pw.sd[ca_p + ".sampling_offsets.bias"].detach().float(),
+                 pw.sd[ca_p + ".attention_weights.bias"].detach().float()], 0), dtype=torch.float32)
+            ops.append(GemmOp(self.xdec, w_oa, rq, lp3, d, [seg(oa, 0, lp3, ldo=ld_oa, bias=b_oa)], A2=self.qpos))
+            ops.append(MsdaFusedOp(self.values[li], self.shapes_t, self.lsi_t, oa, ld_oa, M * L * P * 2, self.ref,
+                                   self.vr, ca, B=B, S=S, M=M, D=D, L=L, Q=nq, P=P))
+            ops.append(GemmOp(ca, pw.w(ca_p + ".output_proj.weight"), rq, d, d, [
+                seg(y, 0, d, ldo=d, bias=pw.f(ca_p + ".output_proj.bias"), res=self.xdec, ldres=d)]))
+            ops.append(LayerNormOp(y, pw.f(lay + ".norm2.weight"), pw.f(lay + ".norm2.bias"), self.xdec, rq, d, 1e-5))
+            ops.append(GemmOp(self.xdec, pw.w(lay + ".linear1.weight"), rq, cfg.dim_feedforward, d, [
+                seg(ffn, 0, cfg.dim_feedforward, ldo=cfg.dim_feedforward, bias=pw.f(lay + ".linear1.bias"), act=ACT_RELU)]))
+            ops.append(GemmOp(ffn, pw.w(lay + ".linear2.weight"), rq, d, cfg.dim_feedforward, [
+                seg(y, 0, d, ldo=d, bias=pw.f(lay + ".linear2.bias"), res=self.xdec, ldres=d)]))
+            ops.append(LayerNormOp(y, pw.f(lay + ".norm3.weight"), pw.f(lay + ".norm3.bias"), self.xdec, rq, d, 1e-5))
+            ops.append(LayerNormOp(self.xdec, pw.f(f"{t}.decoder.norm.weight"), pw.f(f"{t}.decoder.norm.bias"),
+                                   self.hs[li], rq, d, 1e-5))
+        # ---- heads on all decoder layers at once
+        rh = nl * rq
+        hs2 = self.hs.view(rh, d)
+        h1, h2 = z(rh, d), z(rh, d)
+        self.delta = z(rh, 4)
+        self.logits = z(rh, self.ldc)
+        bb = "bbox_embed.layers"
+        ops.append(GemmOp(hs2, pw.w(bb + ".0.weight"), rh, d, d, [seg(h1, 0, d, ldo=d, bias=pw.f(bb + ".0.bias"), act=ACT_RELU)]))
+        ops.append(GemmOp(h1, pw.w(bb + ".1.weight"), rh, d, d, [seg(h2, 0, d, ldo=d, bias=pw.f(bb + ".1.bias"), act=ACT_RELU)]))
+        ops.append(GemmOp(h2, pw.w(bb + ".2.weight"), rh, 4, d, [seg(self.delta, 0, 4, ldo=4, bias=pw.f(bb + ".2.bias"))]))
+        ops.append(GemmOp(hs2, pw.w("class_embed.weight"), rh, self.ncls, d, [
+            seg(self.logits, 0, self.ncls, ldo=self.ldc, bias=pw.f("class_embed.bias"))]))
+        self.query_feat = pw.w("query_feat.weight", lambda w_: w_[:nq], "g0")
+        self.refpoint = pw.f("refpoint_embed.weight", lambda w_: w_[:nq], "g0")
+        self._prop_cache = None
+
+    # ------------------------------------------------------------------------------- per-call host-side glue
+    def _masks(self, mask):
+        """Per-level nearest-resized masks (backbone.py:155-158) -> (mask_flat (B,S) bool, valid ratios (B,L,2))."""
+        flat, vr = [], []
+        for (hl, wl) in self.level_hw:
+            m = F.interpolate(mask[None].float(), size=(hl, wl)).to(torch.bool)[0]
+            flat.append(m.flatten(1))
+            vr.append(torch.stack([(~m[:, 0, :]).sum(1).float() / wl, (~m[:, :, 0]).sum(1).float() / hl], -1))
+        return torch.cat(flat, 1), torch.stack(vr, 1)
+
+    def _proposals(self, mask_flat):
+        """Anchor proposals + validity (transformer.py:71-125, unsigmoid=False). mask_flat None = no padding."""
+        B, dev = self.B, self.dev
+        props, cur = [], 0
+        for lvl, (hl, wl) in enumerate(self.level_hw):
+            gy, gx = torch.meshgrid(torch.arange(hl, dtype=torch.float32, device=dev),
+                                    torch.arange(wl, dtype=torch.float32, device=dev), indexing="ij")
+            grid = torch.stack([gx, gy], -1)[None].expand(B, -1, -1, -1)
+            if mask_flat is None:
+                scale = torch.tensor([wl, hl], dtype=torch.float32, device=dev).view(1, 1, 1, 2)
+            else:
+                m = mask_flat[:, cur:cur + hl * wl].view(B, hl, wl)
+                scale = torch.stack([(~m[:, 0, :]).sum(1), (~m[:, :, 0]).sum(1)], 1).view(B, 1, 1, 2).float()
+            grid = (grid + 0.5) / scale
+            wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+            props.append(torch.cat([grid, wh], -1).view(B, -1, 4))
+            cur += hl * wl
+        props = torch.cat(props, 1)
+        valid = ((props > 0.01) & (props < 0.99)).all(-1)
+        if mask_flat is not None:
+            valid = valid & ~mask_flat
+        props = props * valid.unsqueeze(-1)
+        return props, valid
+
+    @torch.no_grad()
+    def run(self, images, mask=None, forced_topk=None, collect=None):
+        """images (B,3,H,W) on the plan's device; mask (B,H,W) bool or None (= no padding)."""
+        B, S, d, nq, T = self.B, self.S, self.d, self.nq, self.T
+        stream = K.N.stream_ptr(self.dev)
+        self.images.copy_(images)
+        has_pad = mask is not None and bool(mask.any())
+        if has_pad:
+            mask_flat, vr = self._masks(mask)
+            props, valid = self._proposals(mask_flat)
+            self.notpad.copy_((~mask_flat).reshape(-1).to(torch.uint8))
+            self.vr.copy_(vr)
+        else:
+            if self._prop_cache is None:
+                self._prop_cache = self._proposals(None)
+            props, valid = self._prop_cache
+            self.notpad.fill_(1)
+            self.vr.fill_(1.0)
+        self.rowvalid.copy_(valid.reshape(-1).to(torch.uint8))
+        for op in self.ops_backbone:
+            op(stream)
+        for op in self.ops_enc:
+            op(stream)
+        # ---- two-stage selection (group 0 only at inference, transformer.py:229-264)
+        enc_cls = self.enc_cls.view(B, S, self.ldc)[:, :, :self.ncls]
+        cls_max = enc_cls.float().max(-1)[0]
+        topk = torch.topk(cls_max, nq, dim=1)[1] if forced_topk is None else forced_topk.to(self.dev)
+        gi = topk.unsqueeze(-1)
+        self.om_sel.copy_(torch.gather(self.om.view(B, S, d), 1, gi.expand(-1, -1, d)).reshape(B * nq, d))
+        for op in self.ops_sel:
+            op(stream)
+        props_sel = torch.gather(props, 1, gi.expand(-1, -1, 4))
+        ref_ts = reparam(self.enc_delta.view(B, nq, 4).float(), props_sel)
+        enc_logits = torch.gather(enc_cls, 1, gi.expand(-1, -1, self.ncls))
+        # ---- decoder inputs (transformer.py:266-276, :344-364)
+        self.xdec.copy_(self.query_feat.unsqueeze(0).expand(B, -1, -1).reshape(B * nq, d))
+        ref = reparam(self.refpoint.unsqueeze(0).expand(B, -1, -1), ref_ts)
+        self.ref.copy_(ref)
+        ref0 = ref * torch.cat([self.vr[:, 0], self.vr[:, 0]], -1)[:, None]
+        self.sine.copy_(sine_embed(ref0, d // 2).reshape(B * nq, 2 * d))
+        for op in self.ops_dec:
+            op(stream)
+        nl = self.cfg.dec_layers
+        coord = reparam(self.delta.view(nl, B, nq, 4).float(), ref[None]).to(T)
+        cls = self.logits.view(nl, B, nq, self.ldc)[..., :self.ncls].clone()
+        out = {"pred_logits": cls[-1], "pred_boxes": coord[-1]}
+        if self.cfg.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(cls[:-1], coord[:-1])]
+        out["enc_outputs"] = {"pred_logits": enc_logits.clone(), "pred_boxes": ref_ts.to(T)}
+        if collect is not None:
+            collect.update({"topk_idx": topk, "enc.class_max": cls_max, "memory": self.memory.view(B, S, d).clone(),
+                            "taps_cat": self.taps_cat.clone(), "x": self.x.clone(), "hs": self.hs.clone(),
+                            "om": self.om.view(B, S, d).clone()})
+        return out

@@ -1,0 +1,143 @@
+"""Thin Python handles over the C ABI: descriptors are built once (``GemmOp`` / ``AttnOp`` / ``LayerNormOp``) and
+replayed with one ctypes call per launch, so a forward pass is a flat list of pre-built launches."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+from ._native import (A_CONV3x3, A_PATCH16, A_PLAIN, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU,  # noqa: F401
+                      OUT_DECONV2x2, OUT_HEADS, OUT_HEADS_T, OUT_LINEAR, OUT_TOKMAP, AttnDesc, GemmDesc, GemmSeg,
+                      TokLayout)
+
+LOG2E = 1.4426950408889634
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def tok_layout(winmajor=False, hp=0, wp=0, twp=0) -> TokLayout:
+    return TokLayout(1 if winmajor else 0, hp, wp, twp)
+
+
+def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE, scale=1.0, gamma=None, res=None,
+        ldres=0, res_mod=0, out2=None, ld2=0, rowmask=None, p0=0, p1=0, p2=0, in_tok=None, out_tok=None,
+        out_batch_stride=0, out_row_offset=0) -> GemmSeg:
+    """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h)."""
+    s = GemmSeg()
+    s.out, s.out2, s.res = _ptr(out), _ptr(out2), _ptr(res)
+    s.bias, s.gamma, s.rowmask = _ptr(bias), _ptr(gamma), _ptr(rowmask)
+    for t in (bias, gamma):
+        assert t is None or t.dtype == torch.float32
+    assert rowmask is None or rowmask.dtype == torch.uint8
+    s.scale, s.act, s.mode, s.n_begin, s.n_end = float(scale), act, mode, n_begin, n_end
+    s.ldo, s.ld2, s.ldres, s.res_mod = ldo, ld2, ldres, res_mod
+    s.p0, s.p1, s.p2 = p0, p1, p2
+    s.in_tok = in_tok if in_tok is not None else tok_layout()
+    s.out_tok = out_tok if out_tok is not None else tok_layout()
+    s.out_batch_stride, s.out_row_offset = out_batch_stride, out_row_offset
+    return s
+
+
+class GemmOp:
+    """out = epilogue(A_view(M,K) @ W(N,K)^T). Keeps references to every tensor it points at."""
+
+    def __init__(self, A, W, M, N, K, segs, *, lda=None, A2=None, a_mode=A_PLAIN, a_tok=None, conv_cin=0,
+                 conv_stride=1, a_col0=0, conv_hout=0, conv_wout=0, img_h=0, img_w=0, keep=()):
+        N_ = N
+        assert W.dtype == A.dtype and W.is_contiguous()
+        d = GemmDesc()
+        d.A, d.A2, d.W = _ptr(A), _ptr(A2), _ptr(W)
+        d.M, d.N, d.K = M, N_, K
+        d.lda = lda if lda is not None else K
+        d.a_mode = a_mode
+        d.a_tok = a_tok if a_tok is not None else tok_layout()
+        d.conv_cin, d.conv_stride, d.a_col0 = conv_cin, conv_stride, a_col0
+        d.conv_hout, d.conv_wout, d.img_h, d.img_w = conv_hout, conv_wout, img_h, img_w
+        d.nseg = len(segs)
+        for i, s in enumerate(segs):
+            d.seg[i] = s
+        self.desc, self.dtype = d, N.dtype_code(A.dtype)
+        self._keep = (A, A2, W, segs) + tuple(keep)
+        self._fn = N.lib().lwdetr_gemm
+        self._ref = C.byref(d)
+
+    def __call__(self, stream=None):
+        rc = self._fn(self._ref, self.dtype, stream if stream is not None else N.stream_ptr())
+        if rc:
+            N.check(rc, f"gemm M={self.desc.M} N={self.desc.N} K={self.desc.K} a_mode={self.desc.a_mode}")
+
+
+class AttnOp:
+    def __init__(self, Q, K, VT, out, *, B, heads, hd, Tp, ldo, seqs_per_img, seq_tok_stride, keys_per_seq,
+                 sub_stride, sub_len, kind):
+        d = AttnDesc()
+        d.Q, d.K, d.VT, d.out, d.ldo = _ptr(Q), _ptr(K), _ptr(VT), _ptr(out), ldo
+        d.B, d.heads, d.hd, d.Tp = B, heads, hd, Tp
+        d.seqs_per_img, d.seq_tok_stride, d.keys_per_seq = seqs_per_img, seq_tok_stride, keys_per_seq
+        d.sub_stride, d.sub_len, d.kind = sub_stride, sub_len, kind
+        self.desc, self.dtype = d, N.dtype_code(Q.dtype)
+        self._keep = (Q, K, VT, out)
+        self._fn = N.lib().lwdetr_attention
+        self._ref = C.byref(d)
+
+    def __call__(self, stream=None):
+        rc = self._fn(self._ref, self.dtype, stream if stream is not None else N.stream_ptr())
+        if rc:
+            N.check(rc, "attention")
+
+
+class LayerNormOp:
+    def __init__(self, x, gamma, beta, out, M, C_, eps, *, ldx=None, ldo=None, rows_per_batch=0, out_batch_rows=0,
+                 out_row_offset=0):
+        assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+        self.args = (_ptr(x), ldx if ldx is not None else C_, _ptr(gamma), _ptr(beta), _ptr(out),
+                     ldo if ldo is not None else C_, M, C_, float(eps), rows_per_batch, out_batch_rows,
+                     out_row_offset, N.dtype_code(x.dtype))
+        self._keep = (x, gamma, beta, out)
+        self._fn = N.lib().lwdetr_layernorm
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else N.stream_ptr())
+        if rc:
+            N.check(rc, "layernorm")
+
+
+class MsdaFusedOp:
+    def __init__(self, value, shapes, lsi, oa, ld_oa, logit_col, ref, vr, out, *, B, S, M, D, L, Q, P):
+        assert ref.dtype == torch.float32 and vr.dtype == torch.float32
+        assert shapes.dtype == torch.int64 and lsi.dtype == torch.int64
+        self.args = (_ptr(value), _ptr(shapes), _ptr(lsi), _ptr(oa), ld_oa, logit_col, _ptr(ref), _ptr(vr),
+                     _ptr(out), B, S, M, D, L, Q, P, N.dtype_code(value.dtype))
+        self._keep = (value, shapes, lsi, oa, ref, vr, out)
+        self._fn = N.lib().lwdetr_msda_fused_forward
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else N.stream_ptr())
+        if rc:
+            N.check(rc, "msda_fused_forward")
+
+
+# ------------------------------------------------------------------------------------------- one-shot wrappers
+def linear(x, w, bias=None, act=ACT_NONE, res=None, gamma=None):
+    """Plain fused linear on 2-D x (M,K) -> (M,N); convenience for tests and small call sites."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    out = torch.empty(M, Nn, dtype=x.dtype, device=x.device)
+    b = None if bias is None else bias.float().contiguous()
+    g = None if gamma is None else gamma.float().contiguous()
+    s = seg(out, 0, Nn, ldo=Nn, bias=b, act=act, res=res, ldres=Nn if res is not None else 0, gamma=g)
+    GemmOp(x, w.contiguous(), M, Nn, K, [s], keep=(b, g, res))()
+    return out
+
+
+def layernorm(x, gamma, beta, eps):
+    M, C_ = x.shape
+    out = torch.empty_like(x)
+    LayerNormOp(x, gamma.float().contiguous(), beta.float().contiguous(), out, M, C_, eps)()
+    return out
+
+
+def attention_scale(hd: int) -> float:
+    return hd ** -0.5 * LOG2E

@@ -1,0 +1,197 @@
+"""``LWDETR`` / ``PostProcess`` / ``build`` with the reference's API (``models/lwdetr.py:36-216, 509-544, 562-619``).
+
+The module tree (and therefore the state dict) is the reference's; ``forward`` runs the HIP launch plan of
+``lwdetr_amd.engine``. There is no eager / CPU implementation of the forward in this package: on a non-ROCm device,
+or without ``liblwdetr_hip.so``, ``forward`` raises.
+"""
+import copy
+
+import torch
+from torch import nn
+
+from .. import _native
+from ..engine import ForwardPlan, PackedWeights
+from .modules import (MLP, Backbone, Joiner, PositionEmbeddingSine, Transformer, focal_prior_bias)
+from .nested import NestedTensor, nested_tensor_from_tensor_list
+
+
+class LWDETR(nn.Module):
+    def __init__(self, backbone, transformer, num_classes, num_queries, aux_loss=False, group_detr=1,
+                 two_stage=False, lite_refpoint_refine=False, bbox_reparam=False, args=None):
+        super().__init__()
+        if not (two_stage and lite_refpoint_refine and bbox_reparam):
+            raise NotImplementedError("lwdetr_amd implements the published LW-DETR configuration: --two_stage "
+                                      "--bbox_reparam --lite_refpoint_refine (all five model sizes use it)")
+        self.num_queries = num_queries
+        self.transformer = transformer
+        hidden_dim = transformer.d_model
+        self.class_embed = nn.Linear(hidden_dim, num_classes)
+        self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        self.refpoint_embed = nn.Embedding(num_queries * group_detr, 4)
+        self.query_feat = nn.Embedding(num_queries * group_detr, hidden_dim)
+        nn.init.constant_(self.refpoint_embed.weight.data, 0)
+        self.backbone = backbone
+        self.aux_loss, self.group_detr = aux_loss, group_detr
+        self.lite_refpoint_refine, self.bbox_reparam, self.two_stage = lite_refpoint_refine, bbox_reparam, two_stage
+        self.transformer.decoder.bbox_embed = None
+        self.class_embed.bias.data = focal_prior_bias(num_classes)
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        self.transformer.enc_out_bbox_embed = nn.ModuleList(copy.deepcopy(self.bbox_embed) for _ in range(group_detr))
+        self.transformer.enc_out_class_embed = nn.ModuleList(copy.deepcopy(self.class_embed) for _ in range(group_detr))
+        self._export = False
+        self._args = copy.copy(args)
+        self._packed = None      # PackedWeights for the current (device, dtype, parameter versions)
+        self._plans = {}         # (B, H, W) -> ForwardPlan
+
+    # ---- cache invalidation: any change of device / dtype / parameter values drops the packed weights
+    def invalidate_cache(self):
+        self._packed, self._plans = None, {}
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_cache()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_cache()
+        return super().load_state_dict(*a, **k)
+
+    def _weights_token(self):
+        p = self.class_embed.weight
+        return (p.device, p.dtype, sum(q._version for q in self.parameters()))
+
+    def _plan(self, b, h, w):
+        tok = self._weights_token()
+        if self._packed is None or self._packed[0] != tok:
+            dev, dt = tok[0], tok[1]
+            if dev.type != "cuda":
+                raise _native.NativeError("lwdetr_amd: the forward path runs on a ROCm device only - move the model "
+                                          "with .to('cuda'); there is no CPU implementation")
+            if self.training:
+                raise NotImplementedError("lwdetr_amd implements the inference forward; call model.eval()")
+            _native.lib()       # raises loudly when the extension is missing
+            self._packed = (tok, PackedWeights(dict(self.state_dict()), self._args, dev, dt))
+            self._plans = {}
+        key = (b, h, w)
+        if key not in self._plans:
+            if len(self._plans) >= 4:
+                self._plans.pop(next(iter(self._plans)))
+            with torch.cuda.device(tok[0]):
+                self._plans[key] = ForwardPlan(self._packed[1], b, h, w)
+        return self._plans[key]
+
+    @torch.no_grad()
+    def forward(self, samples, targets=None, _forced_topk=None, _collect=None):
+        """samples: NestedTensor | list[Tensor(3,h,w)] | Tensor(B,3,H,W). Returns the reference's output dict:
+        pred_logits (B,nq,C), pred_boxes (B,nq,4) cxcywh, aux_outputs (dec_layers-1 dicts), enc_outputs."""
+        if isinstance(samples, (list, torch.Tensor)):
+            samples = nested_tensor_from_tensor_list(samples)
+        x, mask = samples.tensors, samples.mask
+        assert mask is not None
+        b, _, h, w = x.shape
+        plan = self._plan(b, h, w)
+        with torch.cuda.device(plan.dev):
+            return plan.run(x, mask, forced_topk=_forced_topk, collect=_collect)
+
+    def export(self):
+        """Export-mode forward of the reference (``lwdetr.py:103-109, 176-195``): tensor in, (coords, logits) out."""
+        self._export = True
+        self._forward_origin = self.forward
+        self.forward = self.forward_export
+
+    @torch.no_grad()
+    def forward_export(self, tensors):
+        out = self._forward_origin(tensors)
+        return out["pred_boxes"], out["pred_logits"]
+
+    def update_drop_path(self, drop_path_rate, vit_encoder_num_layers):
+        pass    # training-only knob of the reference (lwdetr.py:205-210); DropPath is identity at inference
+
+    def update_dropout(self, drop_rate):
+        for module in self.transformer.modules():
+            if isinstance(module, nn.Dropout):
+                module.p = drop_rate
+
+
+class PostProcess(nn.Module):
+    """Model output -> per-image {scores, labels, boxes(xyxy, absolute)} (reference ``lwdetr.py:509-544``)."""
+
+    def __init__(self, num_select=300):
+        super().__init__()
+        self.num_select = num_select
+
+    @torch.no_grad()
+    def forward(self, outputs, target_sizes):
+        logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
+        assert len(logits) == len(target_sizes) and target_sizes.shape[1] == 2
+        scores, labels, xyxy = self.select(logits, boxes, target_sizes)
+        return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, xyxy)]
+
+    def select(self, logits, boxes, target_sizes):
+        """Batched form: (scores (B,K), labels (B,K) int64, boxes (B,K,4))."""
+        prob = logits.sigmoid()
+        scores, idx = torch.topk(prob.view(logits.shape[0], -1), self.num_select, dim=1)
+        box_idx = idx // logits.shape[2]
+        labels = idx % logits.shape[2]
+        cx, cy, w, h = boxes.unbind(-1)
+        w, h = w.clamp(min=0.0), h.clamp(min=0.0)       # util/box_ops.py:21-25
+        xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+        xyxy = torch.gather(xyxy, 1, box_idx.unsqueeze(-1).repeat(1, 1, 4))
+        img_h, img_w = target_sizes.unbind(1)
+        xyxy = xyxy * torch.stack([img_w, img_h, img_w, img_h], dim=1)[:, None, :]
+        return scores, labels, xyxy
+
+
+def build(args):
+    """``build_model(args) -> (model, criterion, postprocessors)`` (reference ``lwdetr.py:562-619``).
+
+    The training criterion (Hungarian matcher + losses, ``lwdetr.py:218-506``, ``matcher.py``) is outside this
+    package's scope: when the reference's ``models.lwdetr.SetCriterion`` is importable (i.e. this package is dropped
+    into the reference repository) it is built exactly as the reference does; otherwise ``criterion`` is ``None``."""
+    num_classes = 20 if args.dataset_file != "coco" else 91
+    if args.dataset_file == "o365":
+        num_classes = 366
+    if getattr(args, "position_embedding", "sine") != "sine":
+        raise NotImplementedError("only the sine position embedding of the published configs is supported")
+    backbone = Joiner(
+        Backbone(args.encoder, args.vit_encoder_num_layers, args.window_block_indexes, args.hidden_dim,
+                 args.out_feature_indexes, args.projector_scale),
+        PositionEmbeddingSine(args.hidden_dim // 2))
+    args.num_feature_levels = len(args.projector_scale)
+    transformer = Transformer(
+        d_model=args.hidden_dim, sa_nhead=args.sa_nheads, ca_nhead=args.ca_nheads, num_queries=args.num_queries,
+        num_decoder_layers=args.dec_layers, dim_feedforward=args.dim_feedforward, dropout=args.dropout,
+        group_detr=args.group_detr, two_stage=getattr(args, "two_stage", False),
+        num_feature_levels=args.num_feature_levels, dec_n_points=args.dec_n_points)
+    if getattr(args, "decoder_norm", "LN") != "LN":
+        raise NotImplementedError("decoder_norm must be 'LN' (the published configs)")
+    model = LWDETR(backbone, transformer, num_classes=num_classes, num_queries=args.num_queries,
+                   aux_loss=args.aux_loss, group_detr=args.group_detr, two_stage=args.two_stage,
+                   lite_refpoint_refine=args.lite_refpoint_refine, bbox_reparam=args.bbox_reparam, args=args)
+    model.eval()
+    criterion = _reference_criterion(args, num_classes)
+    postprocessors = {"bbox": PostProcess(num_select=args.num_select)}
+    return model, criterion, postprocessors
+
+
+def _reference_criterion(args, num_classes):
+    try:
+        from models.lwdetr import SetCriterion      # the reference's own training criterion, if co-installed
+        from models.matcher import build_matcher
+    except Exception:
+        return None
+    weight_dict = {"loss_ce": args.cls_loss_coef, "loss_bbox": args.bbox_loss_coef, "loss_giou": args.giou_loss_coef}
+    if args.aux_loss:
+        aux = {}
+        for i in range(args.dec_layers - 1):
+            aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
+        if args.two_stage:
+            aux.update({k + "_enc": v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    crit = SetCriterion(num_classes, matcher=build_matcher(args), weight_dict=weight_dict,
+                        focal_alpha=args.focal_alpha, losses=["labels", "boxes", "cardinality"],
+                        group_detr=args.group_detr, sum_group_losses=getattr(args, "sum_group_losses", False),
+                        use_varifocal_loss=args.use_varifocal_loss,
+                        use_position_supervised_loss=args.use_position_supervised_loss, ia_bce_loss=args.ia_bce_loss)
+    crit.to(torch.device(args.device))
+    return crit

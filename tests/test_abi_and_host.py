@@ -1,0 +1,133 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol of include/lwdetr_hip.h; host-side logic
+(state-dict compatibility, layout helpers, packed weights, post-processing) without touching a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lwdetr_amd
+from helpers import CASES, ROOT, golden_state_dict, load_golden
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from lwdetr_amd import _native
+    return _native
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "lwdetr_hip.h")).read()
+    declared = set(re.findall(r"\b(lwdetr_[a-z0-9_]+)\s*\(", hdr))
+    assert {"lwdetr_msda_forward", "lwdetr_gemm", "lwdetr_attention", "lwdetr_layernorm"} <= declared
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in include/lwdetr_hip.h but not exported"
+
+
+def test_ctypes_structs_match_header_layout(built):
+    """sizeof() of the ctypes mirrors equals what a C compiler computes for the header's structs."""
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "lwdetr_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(lwdetr_tok_layout),' \
+          ' sizeof(lwdetr_gemm_seg), sizeof(lwdetr_gemm_desc), sizeof(lwdetr_attn_desc));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "s.c"), "-o", os.path.join(td, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "s")]).split()]
+    assert sizes == [ctypes.sizeof(built.TokLayout), ctypes.sizeof(built.GemmSeg), ctypes.sizeof(built.GemmDesc),
+                     ctypes.sizeof(built.AttnDesc)]
+
+
+def test_prof_api_without_gpu(built):
+    lib = built.lib()
+    n = lib.lwdetr_prof_num_kernels()
+    names = [lib.lwdetr_prof_kernel_name(i).decode() for i in range(n)]
+    assert "gemm_mfma" in names and "attn_global" in names and "msda_fused_forward" in names
+    assert built.prof_collect() == {}
+
+
+@pytest.mark.parametrize("name", ["tiny_640", "small_640", "medium_640", "large_640", "xlarge_640"])
+def test_state_dict_keys_and_shapes_match_reference(name):
+    g = load_golden(name)
+    model, criterion, post = lwdetr_amd.build_model(lwdetr_amd.get_args(CASES[name][0]))
+    sd = model.state_dict()
+    assert sorted(sd) == [str(k) for k in g["sd_keys"]]
+    ref_shapes = {str(k): str(s) for k, s in zip(g["sd_keys"], g["sd_shapes"])}
+    assert all(",".join(map(str, v.shape)) == ref_shapes[k] for k, v in sd.items())
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    assert set(post) == {"bbox"} and post["bbox"].num_select == lwdetr_amd.get_args(CASES[name][0]).num_select
+
+
+def test_forward_fails_loudly_off_gpu():
+    from lwdetr_amd._native import NativeError
+    model, _, _ = lwdetr_amd.build_model(lwdetr_amd.get_args("tiny"))
+    with pytest.raises(NativeError):
+        model(torch.zeros(1, 3, 128, 128))
+
+
+def test_window_major_position_embedding_matches_reference_order():
+    """abs_pos_winmajor == reference get_abs_pos + reshape/permute (vit.py:26-54, 353-358), incl. pad rows."""
+    from lwdetr_amd.engine import abs_pos_winmajor
+    from oracle.lwdetr_torch import abs_pos
+    c, hp, wp = 8, 12, 8
+    pe = torch.randn(1, 197, c)
+    h, w = hp // 4, wp // 4
+    ref = abs_pos(pe, hp, wp).reshape(1, 4, h, 4, w, c).permute(0, 1, 3, 2, 4, 5).reshape(16, h * w, c)
+    got = abs_pos_winmajor(pe, hp, wp, 8).reshape(16, 8, c)
+    assert torch.allclose(got[:, :h * w], ref, atol=1e-6) and got[:, h * w:].abs().max() == 0
+
+
+def test_convx_folding_and_gemm_weight_layouts():
+    """BN folding + (Cout, tap*Cin) layout reproduce conv->BN; deconv layout reproduces conv_transpose2d."""
+    from lwdetr_amd.engine import PackedWeights
+    g = torch.Generator().manual_seed(0)
+    sd = {"p.conv.weight": torch.randn(6, 4, 3, 3, generator=g), "p.bn.weight": torch.rand(6, generator=g) + 0.5,
+          "p.bn.bias": torch.randn(6, generator=g), "p.bn.running_mean": torch.randn(6, generator=g),
+          "p.bn.running_var": torch.rand(6, generator=g) + 0.5}
+    pw = PackedWeights(sd, None, torch.device("cpu"), torch.float32)
+    wk, b = pw.convx("p")
+    x = torch.randn(2, 4, 5, 7, generator=g)
+    ref = F.batch_norm(F.conv2d(x, sd["p.conv.weight"], padding=1), sd["p.bn.running_mean"], sd["p.bn.running_var"],
+                       sd["p.bn.weight"], sd["p.bn.bias"], False, eps=1e-5)
+    cols = F.unfold(x, 3, padding=1).view(2, 4, 9, 35).permute(0, 3, 2, 1).reshape(2, 35, 36)     # k = tap*Cin + ci
+    got = (cols @ wk.t() + b).permute(0, 2, 1).reshape(2, 6, 5, 7)
+    assert torch.allclose(got, ref, atol=1e-5)
+    wd = torch.randn(4, 3, 2, 2, generator=g)
+    wl = wd.permute(2, 3, 1, 0).reshape(12, 4)                          # engine layout: n = (dy*2+dx)*Cout + co
+    y = (x.permute(0, 2, 3, 1) @ wl.t()).reshape(2, 5, 7, 2, 2, 3).permute(0, 5, 1, 3, 2, 4).reshape(2, 3, 10, 14)
+    assert torch.allclose(y, F.conv_transpose2d(x, wd, stride=2), atol=1e-5)
+
+
+def test_postprocess_matches_golden_on_reference_outputs():
+    g = load_golden("small_640")
+    post = lwdetr_amd.models.PostProcess(300)
+    out = {"pred_logits": torch.from_numpy(g["pred_logits"]), "pred_boxes": torch.from_numpy(g["pred_boxes"])}
+    res = post(out, torch.tensor([[480.0, 640.0]] * 2))
+    assert np.allclose(torch.stack([r["scores"] for r in res]).numpy(), g["post_scores"], atol=1e-6)
+    assert np.array_equal(torch.stack([r["labels"] for r in res]).numpy(), g["post_labels"])
+    assert np.allclose(torch.stack([r["boxes"] for r in res]).numpy(), g["post_boxes"], atol=1e-3)
+
+
+def test_nested_tensor_padding_contract():
+    from lwdetr_amd.models import nested_tensor_from_tensor_list
+    nt = nested_tensor_from_tensor_list([torch.ones(3, 64, 128), torch.ones(3, 128, 64)])
+    assert nt.tensors.shape == (2, 3, 128, 128) and nt.mask.dtype == torch.bool
+    assert not nt.mask[0, :64, :].any() and nt.mask[0, 64:, :].all() and nt.mask[1, :, 64:].all()
+    t, m = nested_tensor_from_tensor_list(torch.zeros(2, 3, 64, 64)).decompose()
+    assert not m.any()
+
+
+def test_synthetic_weights_are_machine_independent():
+    """The integer-hash generator is pinned bit-for-bit (goldens were produced from exactly these tensors)."""
+    import zlib
+    from lwdetr_amd.synth import synth_images, synth_param, uniform01
+    assert uniform01(12345, 3).tolist() == [0.01582909387275222, 0.5738614103347701, 0.10545253817227374]
+    v = synth_param("backbone.0.encoder.blocks.0.attn.qkv.weight", (576, 192))
+    assert zlib.crc32(v.numpy().tobytes()) == 2369530295
+    assert zlib.crc32(synth_images(1, 64, 64).numpy().tobytes()) == 1422412767

@@ -1,0 +1,227 @@
+"""GPU: every HIP kernel of liblwdetr_hip.so against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(_dev())
+
+
+def _relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(300, 192, 192), (1000, 91, 256), (257, 4, 256), (4096, 576, 192), (513, 768, 2048)])
+def test_gemm_linear_bias_act_res(dtype, mnk):
+    from lwdetr_amd import kernels as K
+    m, n, k = mnk
+    x, w = _rand(m, k, dtype=dtype, seed=1), _rand(n, k, dtype=dtype, scale=k ** -0.5, seed=2)
+    b, g = _rand(n, seed=3), _rand(n, seed=4)
+    r = _rand(m, n, dtype=dtype, seed=5)
+    for act, fn in [(K.ACT_NONE, lambda t: t), (K.ACT_RELU, F.relu), (K.ACT_GELU, F.gelu), (K.ACT_SILU, F.silu)]:
+        out = K.linear(x, w, b, act=act)
+        ref = fn(x.float() @ w.float().t() + b)
+        assert _relerr(out, ref) < TOL[dtype], (act, _relerr(out, ref))
+    out = K.linear(x, w, b, res=r, gamma=g)
+    ref = r.float() + g * (x.float() @ w.float().t() + b)
+    assert _relerr(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [16, 32, 64])
+def test_gemm_qkv_head_layouts(dtype, hd):
+    """Three column segments: Q (HEADS, bias, scale), K (HEADS), V^T (HEADS_T, bias) - transpose-detecting data."""
+    from lwdetr_amd import kernels as K
+    heads, b, tp = 12, 2, 104
+    c = heads * hd
+    x = _rand(b * tp, c, dtype=dtype, seed=1)
+    w = _rand(3 * c, c, dtype=dtype, scale=c ** -0.5, seed=2)
+    qb, vb = _rand(c, seed=3), _rand(c, seed=4)
+    q = torch.zeros(b, heads, tp, hd, dtype=dtype, device=_dev())
+    k = torch.zeros_like(q)
+    vt = torch.zeros(b, heads, hd, tp, dtype=dtype, device=_dev())
+    K.GemmOp(x, w, b * tp, 3 * c, c, [
+        K.seg(q, 0, c, mode=K.OUT_HEADS, bias=qb, scale=0.37, p0=tp, p1=hd, p2=heads),
+        K.seg(k, c, 2 * c, mode=K.OUT_HEADS, p0=tp, p1=hd, p2=heads),
+        K.seg(vt, 2 * c, 3 * c, mode=K.OUT_HEADS_T, bias=vb, p0=tp, p1=hd, p2=heads)])()
+    y = x.float() @ w.float().t()
+    sp = lambda t: t.reshape(b, tp, heads, hd).permute(0, 2, 1, 3)
+    assert _relerr(q, sp((y[:, :c] + qb) * 0.37)) < TOL[dtype]
+    assert _relerr(k, sp(y[:, c:2 * c])) < TOL[dtype]
+    assert _relerr(vt, sp(y[:, 2 * c:] + vb).transpose(2, 3)) < TOL[dtype]
+
+
+def _to_winmajor(x_bhwc, twp):
+    """(B, Hp, Wp, C) -> (B*16*twp, C) window-major padded rows (reference order vit.py:357-358)."""
+    b, hp, wp, c = x_bhwc.shape
+    h, w = hp // 4, wp // 4
+    t = x_bhwc.reshape(b, 4, h, 4, w, c).permute(0, 1, 3, 2, 4, 5).reshape(b, 16, h * w, c)
+    out = torch.zeros(b, 16, twp, c, dtype=x_bhwc.dtype, device=x_bhwc.device)
+    out[:, :, :h * w] = t
+    return out.reshape(b * 16 * twp, c)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw", [(128, 192), (192, 192)])
+def test_gemm_patch_embed_window_major(dtype, hw):
+    from lwdetr_amd import kernels as K
+    from lwdetr_amd.engine import _ceil4
+    hh, ww = hw
+    b, c = 2, 192
+    hp, wp = hh // 16, ww // 16
+    twp = _ceil4((hp // 4) * (wp // 4))
+    img = _rand(b, 3, hh, ww, dtype=dtype, seed=1)
+    w = _rand(c, 3, 16, 16, dtype=dtype, scale=768 ** -0.5, seed=2)
+    bias = _rand(c, seed=3)
+    pos = _rand(16 * twp, c, dtype=dtype, seed=4)
+    out = torch.zeros(b * 16 * twp, c, dtype=dtype, device=_dev())
+    tok = K.tok_layout(True, hp, wp, twp)
+    K.GemmOp(img, w.reshape(c, -1).contiguous(), b * 16 * twp, c, 768,
+             [K.seg(out, 0, c, ldo=c, bias=bias, res=pos, ldres=c, res_mod=16 * twp)], a_mode=K.A_PATCH16, a_tok=tok,
+             img_h=hh, img_w=ww)()
+    ref = F.conv2d(img.float(), w.float(), bias, stride=16).permute(0, 2, 3, 1)
+    ref = _to_winmajor(ref, twp).reshape(b, 16 * twp, c) + pos.float()
+    valid = _to_winmajor(torch.ones(b, hp, wp, 1, device=_dev()), twp).reshape(b, 16 * twp, 1) > 0
+    err = ((out.float().reshape(b, 16 * twp, c) - ref) * valid).abs().max() / ref.abs().max()
+    assert err.item() < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride,winmajor", [(1, False), (2, True), (1, True), (2, False)])
+def test_gemm_conv3x3(dtype, stride, winmajor):
+    from lwdetr_amd import kernels as K
+    b, hp, wp, cin, cout, ctot, col0 = 2, 12, 16, 64, 96, 160, 32
+    x = _rand(b, hp, wp, ctot, dtype=dtype, seed=1)
+    w = _rand(cout, cin, 3, 3, dtype=dtype, scale=(9 * cin) ** -0.5, seed=2)
+    bias = _rand(cout, seed=3)
+    twp = (hp // 4) * (wp // 4)
+    a = _to_winmajor(x, twp) if winmajor else x.reshape(-1, ctot)
+    ho, wo = (hp - 1) // stride + 1, (wp - 1) // stride + 1
+    out = torch.zeros(b * ho * wo, cout, dtype=dtype, device=_dev())
+    K.GemmOp(a.contiguous(), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous(), b * ho * wo, cout, 9 * cin,
+             [K.seg(out, 0, cout, ldo=cout, bias=bias, act=K.ACT_SILU)], lda=ctot, a_mode=K.A_CONV3x3,
+             a_tok=K.tok_layout(winmajor, hp, wp, twp), conv_cin=cin, conv_stride=stride, a_col0=col0, conv_hout=ho,
+             conv_wout=wo)()
+    xin = x[..., col0:col0 + cin].float().permute(0, 3, 1, 2)
+    ref = F.silu(F.conv2d(xin, w.float(), bias, stride=stride, padding=1)).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert _relerr(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_deconv2x2_and_tokmap(dtype):
+    from lwdetr_amd import kernels as K
+    b, hp, wp, cin, cout = 2, 8, 12, 64, 32
+    twp = (hp // 4) * (wp // 4)
+    x = _rand(b, hp, wp, cin, dtype=dtype, seed=1)
+    a = _to_winmajor(x, twp)
+    win = K.tok_layout(True, hp, wp, twp)
+    # transposed conv 2x2 stride 2 with pixel shuffle into a wider concat buffer
+    w = _rand(cin, cout, 2, 2, dtype=dtype, scale=cin ** -0.5, seed=2)
+    bias = _rand(cout, seed=3)
+    ntot, off = 3 * cout, cout
+    out = torch.zeros(b * 4 * hp * wp, ntot, dtype=dtype, device=_dev())
+    K.GemmOp(a, w.permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous(), a.shape[0], 4 * cout, cin,
+             [K.seg(out[:, off:], 0, 4 * cout, mode=K.OUT_DECONV2x2, ldo=ntot, bias=bias.repeat(4).contiguous(), p0=cout,
+                    in_tok=win, out_tok=K.tok_layout(False, 2 * hp, 2 * wp, 0), out_batch_stride=4 * hp * wp * ntot)])()
+    ref = F.conv_transpose2d(x.float().permute(0, 3, 1, 2), w.float(), bias, stride=2).permute(0, 2, 3, 1)
+    assert _relerr(out[:, off:off + cout], ref.reshape(-1, cout)) < TOL[dtype]
+    # TOKMAP: window-major rows -> raster rows at a row offset inside a (B, S, n) buffer
+    n, s_total, row_off = 64, hp * wp + 7, 7
+    wl = _rand(n, cin, dtype=dtype, scale=cin ** -0.5, seed=4)
+    o2 = torch.zeros(b * s_total, n, dtype=dtype, device=_dev())
+    K.GemmOp(a, wl, a.shape[0], n, cin, [K.seg(o2, 0, n, mode=K.OUT_TOKMAP, ldo=n, in_tok=win,
+                                               out_tok=K.tok_layout(False, hp, wp, 0), out_batch_stride=s_total * n,
+                                               out_row_offset=row_off)])()
+    ref2 = (x.float().reshape(b, hp * wp, cin) @ wl.float().t())
+    assert _relerr(o2.reshape(b, s_total, n)[:, row_off:], ref2) < TOL[dtype]
+
+
+def _attn_ref(q, k, v, valid):
+    s = (q.float() @ k.float().transpose(-2, -1))
+    s = s.masked_fill(~valid[None, None, None, :], float("-inf"))
+    return s.softmax(-1) @ v.float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [16, 32, 64])
+@pytest.mark.parametrize("geom", ["window100", "global1600", "holes", "decoder300"])
+def test_attention(dtype, hd, geom):
+    from lwdetr_amd import kernels as K
+    heads, b = 3, 2
+    if geom == "window100":
+        twp, tw, spi = 100, 100, 16
+    elif geom == "global1600":
+        twp, tw, spi = 100, 100, 1
+    elif geom == "holes":          # 15x15 windows padded to 228 rows (960x960 geometry), scaled down: 3x3 -> 12
+        twp, tw, spi = 12, 9, 1
+    else:
+        twp, tw, spi = 300, 300, 1
+    tp = 16 * twp if geom != "decoder300" else 300
+    q = _rand(b, heads, tp, hd, dtype=dtype, seed=1)
+    k = _rand(b, heads, tp, hd, dtype=dtype, seed=2)
+    v = _rand(b, heads, tp, hd, dtype=dtype, seed=3)
+    # spike one key against one query so the online-softmax rescale branch is exercised late in the sequence
+    k[0, 0, tp - 3] = q[0, 0, 5] * 4
+    scale = K.attention_scale(hd)
+    qs = (q.float() * scale).to(dtype)
+    out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())
+    keys = twp if spi == 16 else tp
+    K.AttnOp(qs, k, v.transpose(2, 3).contiguous(), out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd,
+             seqs_per_img=spi, seq_tok_stride=twp if spi == 16 else tp, keys_per_seq=keys, sub_stride=twp,
+             sub_len=tw, kind=0)()
+    o = out.reshape(b, tp, heads, hd).permute(0, 2, 1, 3).float()
+    qn = qs.float() / math.log2(math.e)      # kernel works in the log2 domain
+    valid = (torch.arange(tp, device=_dev()) % twp) < tw
+    if spi == 16:
+        refs = []
+        for wi in range(16):
+            sl = slice(wi * twp, (wi + 1) * twp)
+            refs.append(_attn_ref(qn[:, :, sl], k[:, :, sl], v[:, :, sl], valid[sl]))
+        ref = torch.cat(refs, 2)
+    else:
+        ref = _attn_ref(qn, k, v, valid)
+    err = ((o - ref)[:, :, valid]).abs().max().item()
+    assert err < {torch.float32: 2e-5, torch.float16: 6e-3, torch.bfloat16: 4e-2}[dtype], err
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [192, 256, 384, 768])
+def test_layernorm(dtype, c):
+    from lwdetr_amd import kernels as K
+    m = 1003
+    x = _rand(m, c, dtype=dtype, seed=1) * 3 + 0.5
+    g, b = _rand(c, seed=2), _rand(c, seed=3)
+    out = K.layernorm(x, g, b, 1e-6)
+    ref = F.layer_norm(x.float(), (c,), g, b, 1e-6)
+    assert (out.float() - ref).abs().max().item() < {torch.float32: 2e-5, torch.float16: 8e-3, torch.bfloat16: 6e-2}[dtype]
+    # batched row remap (projector LayerNorm writing into a level slice of memory)
+    rows, s_total, off = 50, 64, 9
+    xb = _rand(2 * rows, c, dtype=dtype, seed=4)
+    ob = torch.zeros(2 * s_total, c, dtype=dtype, device=_dev())
+    K.LayerNormOp(xb, g, b, ob, 2 * rows, c, 1e-6, rows_per_batch=rows, out_batch_rows=s_total, out_row_offset=off)()
+    refb = F.layer_norm(xb.float(), (c,), g, b, 1e-6).reshape(2, rows, c)
+    assert (ob.reshape(2, s_total, c)[:, off:off + rows].float() - refb).abs().max().item() < 6e-2
+
+
+def test_gemm_rejects_bad_arguments():
+    from lwdetr_amd import kernels as K
+    from lwdetr_amd._native import NativeError
+    x, w = _rand(8, 48), _rand(8, 48)
+    with pytest.raises(NativeError):
+        K.linear(x, w)                       # K not a multiple of 32

@@ -1,0 +1,119 @@
+"""GPU: end-to-end parity of the HIP forward path with (a) the committed reference goldens and (b) the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lwdetr_amd
+from helpers import CASES, ROOT, case_batch, golden_state_dict, load_golden, sample_idx
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FP32_TOL = 1e-3          # north star: box / logit tensors within 1e-3 in fp32
+
+
+def _model(size, sd, dtype=torch.float32):
+    model, _crit, post = lwdetr_amd.build_model(lwdetr_amd.get_args(size))
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV).to(dtype).eval(), post
+
+
+def _diffs(out, g):
+    d = {"pred_logits": np.abs(out["pred_logits"].float().cpu().numpy() - g["pred_logits"]).max(),
+         "pred_boxes": np.abs(out["pred_boxes"].float().cpu().numpy() - g["pred_boxes"]).max(),
+         "enc_logits": np.abs(out["enc_outputs"]["pred_logits"].float().cpu().numpy() - g["enc_logits"]).max(),
+         "enc_boxes": np.abs(out["enc_outputs"]["pred_boxes"].float().cpu().numpy() - g["enc_boxes"]).max()}
+    for j, aux in enumerate(out["aux_outputs"]):
+        d[f"aux{j}_logits"] = np.abs(aux["pred_logits"].float().cpu().numpy() - g[f"aux{j}_logits"]).max()
+        d[f"aux{j}_boxes"] = np.abs(aux["pred_boxes"].float().cpu().numpy() - g[f"aux{j}_boxes"]).max()
+    return {k: float(v) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fp32_matches_reference_golden(name):
+    """fp32 HIP path vs the unmodified reference's CPU outputs: every output tensor within 1e-3, slot-wise, with the
+    model's own two-stage top-k (no teacher forcing) - the selection itself must reproduce the reference's."""
+    g = load_golden(name)
+    size, images, mask = case_batch(name)
+    model, post = _model(size, golden_state_dict(g))
+    col = {}
+    out = model(lwdetr_amd.models.NestedTensor(images.to(DEV), mask.to(DEV)), _collect=col)
+    same_slots = float((col["topk_idx"].cpu().numpy() == g["topk_idx"]).mean())
+    d = _diffs(out, g)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_fp32_{name}.json"), "w") as f:
+        json.dump({"diffs": d, "topk_same_slots": same_slots}, f)
+    assert np.abs(col["enc.class_max"].cpu().numpy() - g["enc_class_max"]).max() < FP32_TOL
+    assert same_slots == 1.0, f"two-stage top-k differs from the reference in {1 - same_slots:.2%} of slots"
+    assert max(d.values()) < FP32_TOL, d
+    # PostProcess on the HIP outputs reproduces the reference's detections
+    res = post["bbox"](out, torch.tensor([[480.0, 640.0]] * images.shape[0], device=DEV))
+    assert np.abs(torch.stack([r["scores"] for r in res]).cpu().numpy() - g["post_scores"]).max() < 1e-4
+    assert (torch.stack([r["labels"] for r in res]).cpu().numpy() == g["post_labels"]).mean() > 0.99
+
+
+@pytest.mark.parametrize("name", ["tiny_640", "small_padded", "large_padded"])
+def test_fp32_stages_match_oracle(name):
+    """Stage-level comparison against the torch restatement (same weights/inputs): localises a failing kernel."""
+    from oracle import lwdetr_torch as O
+    g = load_golden(name)
+    size, images, mask = case_batch(name)
+    sd = golden_state_dict(g)
+    cfg = lwdetr_amd.get_args(size)
+    col_o = {}
+    with torch.no_grad():
+        exp = O.forward(sd, cfg, images, mask, collect=col_o)
+    model, _ = _model(size, sd)
+    col = {}
+    out = model(lwdetr_amd.models.NestedTensor(images.to(DEV), mask.to(DEV)), _collect=col, _forced_topk=exp["topk_idx"])
+    mem = col["memory"].float().cpu()
+    assert (mem - col_o["memory"]).abs().max().item() < 2e-4
+    assert (col["enc.class_max"].cpu() - col_o["enc.class_max"]).abs().max().item() < 2e-4
+    nl = cfg.dec_layers
+    hs = col["hs"].float().cpu().view(nl, images.shape[0], cfg.num_queries, -1)
+    for li in range(nl):
+        assert (hs[li] - col_o[f"dec.layer{li}"]).abs().max().item() < 5e-4, li
+    assert (out["pred_logits"].float().cpu() - exp["pred_logits"]).abs().max().item() < 5e-4
+    assert (out["pred_boxes"].float().cpu() - exp["pred_boxes"]).abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize("name,dtype,tol_mem,tol_out", [("small_640", torch.float16, 0.05, 0.15),
+                                                         ("medium_640", torch.bfloat16, 0.3, 0.8),
+                                                         ("xlarge_960", torch.float16, 0.08, 0.25)])
+def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_out):
+    """fp16 / bf16 compute (BASELINE configs 2, 3, 5): compared with teacher-forced two-stage indices - slot-wise
+    comparison under a free top-k is meaningless at these precisions; the selected SET is checked."""
+    g = load_golden(name)
+    size, images, mask = case_batch(name)
+    model, _ = _model(size, golden_state_dict(g), dtype)
+    col = {}
+    forced = torch.from_numpy(g["topk_idx"]).to(DEV)
+    out = model(images.to(DEV), _collect=col, _forced_topk=forced)
+    d = _diffs(out, g)
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_{str(dtype).split('.')[-1]}_{name}.json"), "w") as f:
+        json.dump(d, f)
+    assert np.abs(col["enc.class_max"].cpu().numpy() - g["enc_class_max"]).max() < tol_mem
+    assert max(d["pred_logits"], d["enc_logits"]) < tol_out, d
+    assert max(d["pred_boxes"], d["enc_boxes"]) < tol_out * 0.2, d
+    free = model(images.to(DEV), _collect=col)
+    a, b = col["topk_idx"].cpu().numpy(), g["topk_idx"]
+    overlap = np.mean([len(set(x) & set(y)) / len(y) for x, y in zip(a, b)])
+    assert overlap > 0.9, overlap
+    assert torch.isfinite(free["pred_logits"].float()).all()
+
+
+def test_state_dict_roundtrip_and_reload_invalidates_cache():
+    g = load_golden("tiny_192x256")
+    size, images, mask = case_batch("tiny_192x256")
+    sd = golden_state_dict(g)
+    model, _ = _model(size, sd)
+    o1 = model(lwdetr_amd.models.NestedTensor(images.to(DEV), mask.to(DEV)))["pred_logits"].clone()
+    sd2 = {k: (v * 1.01 if v.is_floating_point() else v) for k, v in sd.items()}
+    model.load_state_dict(sd2)
+    o2 = model(lwdetr_amd.models.NestedTensor(images.to(DEV), mask.to(DEV)))["pred_logits"]
+    assert (o1 - o2).abs().max().item() > 1e-4
+    model.load_state_dict(sd)
+    o3 = model([img for img in images.to(DEV)])["pred_logits"]
+    assert torch.equal(o1, o3)                       # deterministic: same launches, same bits

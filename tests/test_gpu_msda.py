@@ -1,0 +1,115 @@
+"""GPU: the HIP deformable-attention op behind the reference's operator API, against the reference's KAT vectors
+(models/ops/test.py), the C restatement oracle and size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lsi(shapes):
+    return torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1])).contiguous()
+
+
+def _run(value, shapes, loc, aw, step=64):
+    from lwdetr_amd.ops import MSDeformAttnFunction
+    shapes = torch.as_tensor(shapes, dtype=torch.int64, device=DEV)
+    b = value.shape[0]
+    return MSDeformAttnFunction.apply(value.to(DEV).contiguous(), shapes, _lsi(shapes), loc.to(DEV).contiguous(),
+                                      aw.to(DEV).contiguous(), step if b % step == 0 else b)
+
+
+def test_reference_kat_double_and_float():
+    g = load_golden("msda_op_kat")
+    out = _run(torch.from_numpy(g["double_value"]), g["shapes"], torch.from_numpy(g["double_loc"]),
+               torch.from_numpy(g["double_aw"]), step=2)
+    assert torch.allclose(out.cpu(), torch.from_numpy(g["double_out"]))          # models/ops/test.py:56
+    out = _run(torch.from_numpy(g["float_value"]), g["shapes"], torch.from_numpy(g["float_loc"]),
+               torch.from_numpy(g["float_aw"]), step=2)
+    assert torch.allclose(out.cpu(), torch.from_numpy(g["float_out"]), rtol=1e-2, atol=1e-3)   # test.py:82
+    assert (out.cpu() - torch.from_numpy(g["float_out"])).abs().max() < 1e-7
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-6), (torch.float16, 2e-2), (torch.bfloat16, 1e-1)])
+def test_out_of_bounds_golden(dtype, tol):
+    g = load_golden("msda_op_kat")
+    out = _run(torch.from_numpy(g["oob_value"]).to(dtype), g["oob_shapes"], torch.from_numpy(g["oob_loc"]).to(dtype),
+               torch.from_numpy(g["oob_aw"]).to(dtype))
+    assert (out.float().cpu() - torch.from_numpy(g["oob_out"])).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("cfg", [dict(B=8, shapes=[(40, 40)], M=16, D=16, Q=300, P=2),
+                                 dict(B=3, shapes=[(80, 80), (20, 20)], M=24, D=16, Q=300, P=4),
+                                 dict(B=2, shapes=[(7, 5), (3, 9), (4, 4)], M=2, D=8, Q=33, P=3),
+                                 dict(B=2, shapes=[(9, 6)], M=3, D=5, Q=17, P=1)])
+def test_against_c_oracle(cfg):
+    from oracle import msda_c
+    rng = np.random.default_rng(0)
+    shapes = np.array(cfg["shapes"], dtype=np.int64)
+    s = int((shapes[:, 0] * shapes[:, 1]).sum())
+    b, m, d, q, p, l = cfg["B"], cfg["M"], cfg["D"], cfg["Q"], cfg["P"], len(cfg["shapes"])
+    value = rng.standard_normal((b, s, m, d)).astype(np.float32)
+    loc = (rng.random((b, q, m, l, p, 2)) * 1.3 - 0.15).astype(np.float32)
+    loc[0, 0, 0, 0, 0] = [(2 + 0.5) / shapes[0, 1], (1 + 0.5) / shapes[0, 0]]     # exactly on a pixel centre
+    aw = rng.random((b, q, m, l, p)).astype(np.float32)
+    aw /= aw.sum((-1, -2), keepdims=True)
+    ref = msda_c.msda_forward(value, shapes, loc, aw)
+    out = _run(torch.from_numpy(value), shapes, torch.from_numpy(loc), torch.from_numpy(aw))
+    assert np.abs(out.cpu().numpy() - ref).max() < 5e-6
+
+
+def test_properties_full_size_and_contract():
+    """BASELINE-size checks that need no oracle: linearity in value and in the weights, zero weights -> zero,
+    and the argument contract of the reference host wrapper (ms_deform_attn_cuda.cu:28-52)."""
+    from lwdetr_amd.ops import MSDeformAttnFunction
+    torch.manual_seed(0)
+    b, shapes, m, d, q, p = 32, [(80, 80), (20, 20)], 24, 16, 300, 4
+    sh = torch.tensor(shapes, dtype=torch.int64, device=DEV)
+    s = 6800
+    v1, v2 = torch.randn(b, s, m, d, device=DEV), torch.randn(b, s, m, d, device=DEV)
+    loc = torch.rand(b, q, m, 2, p, 2, device=DEV) * 1.2 - 0.1
+    aw = torch.rand(b, q, m, 2, p, device=DEV)
+    f = lambda v, a: MSDeformAttnFunction.apply(v, sh, _lsi(sh), loc, a, 64 if b % 64 == 0 else b)
+    o1, o2, o12 = f(v1, aw), f(v2, aw), f(v1 + 2 * v2, aw)
+    assert (o12 - (o1 + 2 * o2)).abs().max().item() < 2e-4
+    assert (f(v1, aw * 0.5) - 0.5 * o1).abs().max().item() < 1e-5
+    assert f(v1, torch.zeros_like(aw)).abs().max().item() == 0.0
+    assert o1.shape == (b, q, m * d)
+    with pytest.raises(RuntimeError):
+        MSDeformAttnFunction.apply(v1.transpose(1, 2), sh, _lsi(sh), loc, aw, 32)       # non-contiguous
+    with pytest.raises(RuntimeError):
+        MSDeformAttnFunction.apply(v1.cpu(), sh, _lsi(sh), loc, aw, 32)                 # wrong device
+    with pytest.raises(RuntimeError):
+        MSDeformAttnFunction.apply(v1[:30].contiguous(), sh, _lsi(sh), loc[:30].contiguous(), aw[:30].contiguous(), 7)
+    empty = MSDeformAttnFunction.apply(v1, sh, _lsi(sh), loc[:, :0].contiguous(), aw[:, :0].contiguous(), 32)
+    assert empty.shape == (b, 0, m * d)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2e-2)])
+@pytest.mark.parametrize("lp", [(1, 2), (2, 4)])
+def test_fused_module_matches_oracle_module(dtype, tol, lp):
+    """MSDeformAttn module (fused prologue kernel) vs the torch restatement of ms_deform_attn.py:96-144."""
+    from lwdetr_amd.ops import MSDeformAttn
+    from lwdetr_amd.synth import synth_state_dict
+    from oracle import lwdetr_torch as O
+    l, p = lp
+    d, m, b, q = 256, 16, 2, 50
+    shapes = [(20, 24), (10, 12)][:l]
+    s = sum(h * w for h, w in shapes)
+    mod = MSDeformAttn(d, l, m, p)
+    sd = synth_state_dict(mod.state_dict(), seed=5)
+    mod.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1)
+    query, memory = torch.randn(b, q, d, generator=g), torch.randn(b, s, d, generator=g)
+    ref_box = torch.rand(b, q, 4, generator=g) * torch.tensor([1, 1, 0.3, 0.3]) + torch.tensor([0, 0, 0.02, 0.02])
+    ref_in = ref_box[:, :, None].expand(-1, -1, l, -1).contiguous()
+    mask = torch.zeros(b, s, dtype=torch.bool)
+    mask[1, -17:] = True
+    exp = O.msda({"x." + k: v for k, v in sd.items()}, "x", query, ref_in, memory, mask, shapes, m, p)
+    sh = torch.tensor(shapes, dtype=torch.int64, device=DEV)
+    mod = mod.to(DEV).to(dtype)
+    out = mod(query.to(DEV, dtype), ref_in.to(DEV, dtype), memory.to(DEV, dtype), sh, _lsi(sh), mask.to(DEV))
+    assert (out.float().cpu() - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item())
