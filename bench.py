@@ -39,15 +39,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="also report p50/p90 single-image latency (bs=1)")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(size, res):
-    """The CPU oracle (a port of the reference's PyTorch CPU path, pinned to reference goldens) timed on this box's
-    host cores on a bounded sample of the same workload."""
+def _cpu_baseline_worker(size, res):
     from oracle import lwdetr_torch as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = torch.get_num_threads()                 # torch's default: the cores this process may actually use
     cfg = lwdetr_amd.get_args(size)
     model, _, _ = lwdetr_amd.build_model(cfg)
     sd = synth_state_dict(model.state_dict(), seed=0)
@@ -60,12 +58,31 @@ def cpu_baseline(size, res):
             O.forward(sd, cfg, x)
             n += 1
         dt = time.time() - t0
-    return {"value": round(b * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} forwards of batch {b} at {res}x{res}, fp32, oracle/lwdetr_torch.py on {cores} threads"}
+    print(json.dumps({"value": round(b * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+                      "sample": f"{n} forwards of batch {b} at {res}x{res}, fp32, oracle/lwdetr_torch.py "
+                                f"(CPU restatement of the reference PyTorch path) on {cores} threads"}))
+
+
+def cpu_baseline(size, res):
+    """The CPU oracle (a port of the reference's PyTorch CPU path, pinned to reference goldens) timed on this box's
+    host cores on a bounded sample of the same workload; runs in a child process under a hard time limit."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--size", size,
+                            "--res", str(res)], capture_output=True, text=True, timeout=150)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001 - the baseline is informational; never lose the GPU measurement
+        return {"value": None, "unit": "images/sec", "cores": None, "kind": "port", "sample": f"failed: {e!r}"[:200]}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
     a = parse()
+    if a.cpu_baseline_worker:
+        return _cpu_baseline_worker(a.size, a.res)
     rank, world, local = ldist.init_from_env()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
@@ -94,9 +111,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    log(f"model built ({a.size}, {a.dtype}); warm-up x{a.warmup}")
     for _ in range(a.warmup):
         step()
     barrier()
+    log("timing")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         det = step()
@@ -107,6 +126,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
     assert torch.isfinite(det).all()
+    log(f"timed {a.steps} steps: {dt / a.steps * 1e3:.3f} ms/step")
     ms_step = dt / a.steps * 1e3
     ips = world * a.batch * a.steps / dt
 
@@ -166,6 +186,7 @@ def main():
         result["latency_bs1_ms"] = {"p50": round(lat[len(lat) // 2], 3), "p90": round(lat[int(len(lat) * 0.9)], 3)}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("cpu baseline (child process)")
         result["cpu_baseline"] = cpu_baseline(a.size, a.res)
 
     if rank == 0:

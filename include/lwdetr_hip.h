@@ -66,13 +66,15 @@ typedef struct {           /* one column segment [n_begin, n_end) of the output 
     const void* res;       /* optional residual, same dtype as out, addressed LINEAR with ldres; row = m % res_mod if res_mod>0 */
     const float* bias;     /* optional (N) f32, indexed by n - n_begin + bias_off */
     const float* gamma;    /* optional (N) f32 LayerScale: out = res + gamma * (acc + bias) */
-    const uint8_t* rowmask;/* optional (M): rows with mask == 0 contribute acc = 0 before bias */
+    const uint8_t* rowmask;/* optional (M): rows with mask == 0 get acc = 0 before bias (rowmask_after = 0, the reference's
+                              masked_fill of the INPUT row) or a zero OUTPUT row (rowmask_after = 1, masked_fill of the result) */
     float scale;           /* multiplies (acc + bias) */
     int act;
     int mode;              /* LWDETR_OUT_* */
     int n_begin, n_end;
     long ldo, ld2, ldres;
     int res_mod;
+    int rowmask_after;
     int p0, p1, p2;        /* HEADS/HEADS_T: p0 = tokens per image Tp, p1 = head_dim, p2 = heads */
     lwdetr_tok_layout in_tok, out_tok;   /* TOKMAP / DECONV2x2: row decode / encode layouts */
     long out_batch_stride; /* TOKMAP / DECONV2x2: elements between images in out (0 = dense) */

@@ -32,7 +32,7 @@ class GemmSeg(C.Structure):
     _fields_ = [("out", C.c_void_p), ("out2", C.c_void_p), ("res", C.c_void_p), ("bias", C.c_void_p),
                 ("gamma", C.c_void_p), ("rowmask", C.c_void_p), ("scale", C.c_float), ("act", C.c_int),
                 ("mode", C.c_int), ("n_begin", C.c_int), ("n_end", C.c_int), ("ldo", C.c_long), ("ld2", C.c_long),
-                ("ldres", C.c_long), ("res_mod", C.c_int), ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int),
+                ("ldres", C.c_long), ("res_mod", C.c_int), ("rowmask_after", C.c_int), ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int),
                 ("in_tok", TokLayout), ("out_tok", TokLayout), ("out_batch_stride", C.c_long),
                 ("out_row_offset", C.c_long)]
 

@@ -36,6 +36,9 @@ _SIZES = {
 
 SIZES = tuple(_SIZES)
 
+VIT_SIZES = {"vit_tiny": (192, 12), "vit_small": (384, 12), "vit_base": (768, 12)}   # models/backbone/backbone.py:46-51
+LEVEL_SCALE = {"P3": 2.0, "P4": 1.0, "P5": 0.5}                                       # models/backbone/backbone.py:124-129
+
 # Algorithmic GFLOP per image (2*MAC; GEMM + conv + attention bmm), SURVEY.md section 2.2 / BASELINE.md section 2.
 GFLOP_PER_IMAGE = {("tiny", 640): 21.40, ("small", 640): 31.76, ("medium", 640): 83.93,
                    ("large", 640): 137.51, ("xlarge", 640): 342.51, ("xlarge", 960): 860.10}

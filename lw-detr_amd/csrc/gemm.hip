@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
         for (int t = 0; t < TT; ++t) {
             const long m = m0 + wm * WM + t * 16 + l15;
             if (m >= d.M) continue;
-            const bool keep = !sg.rowmask || sg.rowmask[m];
+            const bool rm = !sg.rowmask || sg.rowmask[m];
+            const bool keep = rm || sg.rowmask_after, keep_out = rm || !sg.rowmask_after;
             long rowoff = 0; bool row_ok = true;
             int hb = 0, ht = 0; TokPos tp = {0, 0, 0, 1};
             if (sg.mode == LWDETR_OUT_LINEAR) rowoff = m * sg.ldo;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
                     x = apply_act(x, sg.act) * sg.scale;
                     if (sg.gamma && in) x *= sg.gamma[nl + r];
                     if (res && in) x += to_f32<T>(res[res_row + nl + r]);
-                    v[r] = x;
+                    v[r] = keep_out ? x : 0.f;
                 }
                 long off;
                 if (sg.mode == LWDETR_OUT_HEADS) {

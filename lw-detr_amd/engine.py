@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from . import kernels as K
 from .kernels import (A_CONV3x3, A_PATCH16, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, OUT_DECONV2x2, OUT_HEADS,
                       OUT_HEADS_T, OUT_LINEAR, OUT_TOKMAP, AttnOp, GemmOp, LayerNormOp, MsdaFusedOp, seg, tok_layout)
-from .models.modules import LEVEL_SCALE, VIT_SIZES
+from .configs import LEVEL_SCALE, VIT_SIZES
 
 
 def _ceil4(n):
@@ -304,7 +304,7 @@ class ForwardPlan:
             [pw.sd[f"{t}.decoder.layers.{i}.cross_attn.value_proj.bias"].detach().float() for i in range(nl)], 0),
             dtype=torch.float32)
         self.values = [z(B * S, d) for _ in range(nl)]
-        vsegs = [seg(self.values[i], i * d, (i + 1) * d, ldo=d, bias=bv[i * d:], rowmask=self.notpad)
+        vsegs = [seg(self.values[i], i * d, (i + 1) * d, ldo=d, bias=bv[i * d:], rowmask=self.notpad, rowmask_after=True)
                  for i in range(nl)]
         for g0 in range(0, nl, 3):
             grp = vsegs[g0:g0 + 3]
@@ -431,7 +431,7 @@ class ForwardPlan:
     def run(self, images, mask=None, forced_topk=None, collect=None):
         """images (B,3,H,W) on the plan's device; mask (B,H,W) bool or None (= no padding)."""
         B, S, d, nq, T = self.B, self.S, self.d, self.nq, self.T
-        stream = K.N.stream_ptr(self.dev)
+        stream = K._nat.stream_ptr(self.dev)
         self.images.copy_(images)
         has_pad = mask is not None and bool(mask.any())
         if has_pad:

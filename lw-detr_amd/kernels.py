@@ -5,7 +5,7 @@ import math
 
 import torch
 
-from . import _native as N
+from . import _native as _nat
 from ._native import (A_CONV3x3, A_PATCH16, A_PLAIN, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU,  # noqa: F401
                       OUT_DECONV2x2, OUT_HEADS, OUT_HEADS_T, OUT_LINEAR, OUT_TOKMAP, AttnDesc, GemmDesc, GemmSeg,
                       TokLayout)
@@ -22,7 +22,7 @@ def tok_layout(winmajor=False, hp=0, wp=0, twp=0) -> TokLayout:
 
 
 def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE, scale=1.0, gamma=None, res=None,
-        ldres=0, res_mod=0, out2=None, ld2=0, rowmask=None, p0=0, p1=0, p2=0, in_tok=None, out_tok=None,
+        ldres=0, res_mod=0, out2=None, ld2=0, rowmask=None, rowmask_after=False, p0=0, p1=0, p2=0, in_tok=None, out_tok=None,
         out_batch_stride=0, out_row_offset=0) -> GemmSeg:
     """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h)."""
     s = GemmSeg()
@@ -34,6 +34,7 @@ def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE,
     s.scale, s.act, s.mode, s.n_begin, s.n_end = float(scale), act, mode, n_begin, n_end
     s.ldo, s.ld2, s.ldres, s.res_mod = ldo, ld2, ldres, res_mod
     s.p0, s.p1, s.p2 = p0, p1, p2
+    s.rowmask_after = 1 if rowmask_after else 0
     s.in_tok = in_tok if in_tok is not None else tok_layout()
     s.out_tok = out_tok if out_tok is not None else tok_layout()
     s.out_batch_stride, s.out_row_offset = out_batch_stride, out_row_offset
@@ -58,15 +59,15 @@ class GemmOp:
         d.nseg = len(segs)
         for i, s in enumerate(segs):
             d.seg[i] = s
-        self.desc, self.dtype = d, N.dtype_code(A.dtype)
+        self.desc, self.dtype = d, _nat.dtype_code(A.dtype)
         self._keep = (A, A2, W, segs) + tuple(keep)
-        self._fn = N.lib().lwdetr_gemm
+        self._fn = _nat.lib().lwdetr_gemm
         self._ref = C.byref(d)
 
     def __call__(self, stream=None):
-        rc = self._fn(self._ref, self.dtype, stream if stream is not None else N.stream_ptr())
+        rc = self._fn(self._ref, self.dtype, stream if stream is not None else _nat.stream_ptr())
         if rc:
-            N.check(rc, f"gemm M={self.desc.M} N={self.desc.N} K={self.desc.K} a_mode={self.desc.a_mode}")
+            _nat.check(rc, f"gemm M={self.desc.M} N={self.desc.N} K={self.desc.K} a_mode={self.desc.a_mode}")
 
 
 class AttnOp:
@@ -77,15 +78,15 @@ class AttnOp:
         d.B, d.heads, d.hd, d.Tp = B, heads, hd, Tp
         d.seqs_per_img, d.seq_tok_stride, d.keys_per_seq = seqs_per_img, seq_tok_stride, keys_per_seq
         d.sub_stride, d.sub_len, d.kind = sub_stride, sub_len, kind
-        self.desc, self.dtype = d, N.dtype_code(Q.dtype)
+        self.desc, self.dtype = d, _nat.dtype_code(Q.dtype)
         self._keep = (Q, K, VT, out)
-        self._fn = N.lib().lwdetr_attention
+        self._fn = _nat.lib().lwdetr_attention
         self._ref = C.byref(d)
 
     def __call__(self, stream=None):
-        rc = self._fn(self._ref, self.dtype, stream if stream is not None else N.stream_ptr())
+        rc = self._fn(self._ref, self.dtype, stream if stream is not None else _nat.stream_ptr())
         if rc:
-            N.check(rc, "attention")
+            _nat.check(rc, "attention")
 
 
 class LayerNormOp:
@@ -94,14 +95,14 @@ class LayerNormOp:
         assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
         self.args = (_ptr(x), ldx if ldx is not None else C_, _ptr(gamma), _ptr(beta), _ptr(out),
                      ldo if ldo is not None else C_, M, C_, float(eps), rows_per_batch, out_batch_rows,
-                     out_row_offset, N.dtype_code(x.dtype))
+                     out_row_offset, _nat.dtype_code(x.dtype))
         self._keep = (x, gamma, beta, out)
-        self._fn = N.lib().lwdetr_layernorm
+        self._fn = _nat.lib().lwdetr_layernorm
 
     def __call__(self, stream=None):
-        rc = self._fn(*self.args, stream if stream is not None else N.stream_ptr())
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
         if rc:
-            N.check(rc, "layernorm")
+            _nat.check(rc, "layernorm")
 
 
 class MsdaFusedOp:
@@ -109,14 +110,14 @@ class MsdaFusedOp:
         assert ref.dtype == torch.float32 and vr.dtype == torch.float32
         assert shapes.dtype == torch.int64 and lsi.dtype == torch.int64
         self.args = (_ptr(value), _ptr(shapes), _ptr(lsi), _ptr(oa), ld_oa, logit_col, _ptr(ref), _ptr(vr),
-                     _ptr(out), B, S, M, D, L, Q, P, N.dtype_code(value.dtype))
+                     _ptr(out), B, S, M, D, L, Q, P, _nat.dtype_code(value.dtype))
         self._keep = (value, shapes, lsi, oa, ref, vr, out)
-        self._fn = N.lib().lwdetr_msda_fused_forward
+        self._fn = _nat.lib().lwdetr_msda_fused_forward
 
     def __call__(self, stream=None):
-        rc = self._fn(*self.args, stream if stream is not None else N.stream_ptr())
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
         if rc:
-            N.check(rc, "msda_fused_forward")
+            _nat.check(rc, "msda_fused_forward")
 
 
 # ------------------------------------------------------------------------------------------- one-shot wrappers

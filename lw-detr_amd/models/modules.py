@@ -11,10 +11,9 @@ import math
 import torch
 from torch import nn
 
+from ..configs import LEVEL_SCALE, VIT_SIZES
 from ..ops.modules import MSDeformAttn
 
-VIT_SIZES = {"vit_tiny": (192, 12), "vit_small": (384, 12), "vit_base": (768, 12)}   # models/backbone/backbone.py:46-51
-LEVEL_SCALE = {"P3": 2.0, "P4": 1.0, "P5": 0.5}                                       # models/backbone/backbone.py:124-129
 
 
 class _NoCompute(nn.Module):

@@ -81,7 +81,7 @@ def _to_winmajor(x_bhwc, twp):
 @pytest.mark.parametrize("hw", [(128, 192), (192, 192)])
 def test_gemm_patch_embed_window_major(dtype, hw):
     from lwdetr_amd import kernels as K
-    from lwdetr_amd.engine import _ceil4
+    _ceil4 = lambda n: (n + 3) // 4 * 4
     hh, ww = hw
     b, c = 2, 192
     hp, wp = hh // 16, ww // 16
