@@ -64,8 +64,8 @@ typedef struct {           /* one column segment [n_begin, n_end) of the output 
     void* out;             /* destination base */
     void* out2;            /* optional second LINEAR destination (ViT feature taps), row stride ld2 */
     const void* res;       /* optional residual, same dtype as out, addressed LINEAR with ldres; row = m % res_mod if res_mod>0 */
-    const float* bias;     /* optional (N) f32, indexed by n - n_begin + bias_off */
-    const float* gamma;    /* optional (N) f32 LayerScale: out = res + gamma * (acc + bias) */
+    const float* bias;     /* optional f32, indexed by n - n_begin; 16-byte aligned and readable up to ceil8(n_end-n_begin) */
+    const float* gamma;    /* optional f32 LayerScale (same padding rule): out = res + gamma * act(acc + bias) * scale */
     const uint8_t* rowmask;/* optional (M): rows with mask == 0 get acc = 0 before bias (rowmask_after = 0, the reference's
                               masked_fill of the INPUT row) or a zero OUTPUT row (rowmask_after = 1, masked_fill of the result) */
     float scale;           /* multiplies (acc + bias) */

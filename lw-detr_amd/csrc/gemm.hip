@@ -21,6 +21,57 @@ namespace {
 
 constexpr int BK = 32;
 
+// ---- epilogue helpers -------------------------------------------------------------------------------------------
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): GELU stays exact-erf to f32 round-off at a fraction of erff's cost
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.f - poly * __expf(-ax * ax);
+    return x < 0.f ? -e : e;
+}
+__device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == ACT_GELU) return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752440f));
+    if (act == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
+    if (act == ACT_RELU) return x > 0.f ? x : 0.f;
+    return x;
+}
+
+// destination offset of row m (all modes are separable: off = row_offset(m) + col_offset(n)); returns false for pad rows
+__device__ __forceinline__ bool row_offset(const lwdetr_gemm_seg& sg, long m, long& off) {
+    if (sg.mode == LWDETR_OUT_LINEAR) { off = m * sg.ldo; return true; }
+    if (sg.mode == LWDETR_OUT_HEADS) {
+        const int b = (int)(m / sg.p0), t = (int)(m - (long)b * sg.p0);
+        off = ((long)b * sg.p2 * sg.p0 + t) * sg.p1;
+        return true;
+    }
+    const TokPos tp = tok_decode(m, sg.in_tok);
+    const int s = sg.mode == LWDETR_OUT_DECONV2x2 ? 2 : 1;      // DECONV: top-left output pixel of this input pixel
+    off = (long)tp.b * sg.out_batch_stride + (sg.out_row_offset + tok_encode(0, s * tp.y, s * tp.x, sg.out_tok)) * sg.ldo;
+    return tp.valid;
+}
+__device__ __forceinline__ long col_offset(const lwdetr_gemm_seg& sg, int nl) {
+    if (sg.mode == LWDETR_OUT_HEADS) { const int h = nl / sg.p1; return (long)h * sg.p0 * sg.p1 + (nl - h * sg.p1); }
+    if (sg.mode == LWDETR_OUT_DECONV2x2) {
+        const int q4 = nl / sg.p0, co = nl - q4 * sg.p0;
+        return ((long)(q4 >> 1) * sg.out_tok.Wp + (q4 & 1)) * sg.ldo + co;
+    }
+    return nl;
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ void store_run(T* dst, const float* x, int cnt, bool aligned) {
+    if (cnt >= NV && aligned) {
+        typedef T VT __attribute__((ext_vector_type(NV)));
+        VT o;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) o[e] = from_f32<T>(x[e]);
+        *(VT*)dst = o;
+    } else {
+        for (int e = 0; e < NV && e < cnt; ++e) dst[e] = from_f32<T>(x[e]);
+    }
+}
+
 template <typename T, int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -177,93 +228,115 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
         __syncthreads();
     }
 
-    // ---- epilogue
-    T* __restrict__ out = (T*)sg.out;
-    T* __restrict__ out2 = (T*)sg.out2;
-    const T* __restrict__ res = (const T*)sg.res;
+    // ---- epilogue through LDS: accumulators are staged as f32 (64 tile rows per pass), then each thread finishes
+    // runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores, and the mode / activation logic
+    // lives in a small non-unrolled loop instead of being replicated per accumulator register.
+    float* stage = (float*)smem;
+    constexpr int SLD = BN + 4, SLD_T = 64 + 4;
     const int n_end = sg.n_end < d.N ? sg.n_end : d.N;
-    if (!col_orient) {
+    T* __restrict__ out = (T*)sg.out;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+            float* sp = col_orient ? stage + (wn * WN + l15) * SLD_T + g * 4 : stage + l15 * SLD + wn * WN + g * 4;
+            const int fs = col_orient ? 16 * SLD_T : 16, ts = col_orient ? 16 : 16 * SLD;
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const long m = m0 + wm * WM + t * 16 + l15;
-            if (m >= d.M) continue;
-            const bool rm = !sg.rowmask || sg.rowmask[m];
-            const bool keep = rm || sg.rowmask_after, keep_out = rm || !sg.rowmask_after;
-            long rowoff = 0; bool row_ok = true;
-            int hb = 0, ht = 0; TokPos tp = {0, 0, 0, 1};
-            if (sg.mode == LWDETR_OUT_LINEAR) rowoff = m * sg.ldo;
-            else if (sg.mode == LWDETR_OUT_HEADS) { hb = (int)(m / sg.p0); ht = (int)(m - (long)hb * sg.p0); }
-            else {
-                tp = tok_decode(m, sg.in_tok); row_ok = tp.valid;
-                if (sg.mode == LWDETR_OUT_TOKMAP)
-                    rowoff = (long)tp.b * sg.out_batch_stride + (sg.out_row_offset + tok_encode(0, tp.y, tp.x, sg.out_tok)) * sg.ldo;
-            }
-            if (!row_ok) continue;
-            const long res_row = res ? (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres : 0;
+            for (int f = 0; f < FT; ++f)
 #pragma unroll
-            for (int f = 0; f < FT; ++f) {
-                const int n = n0 + wn * WN + f * 16 + g * 4;
-                if (n >= n_end) continue;
-                const int nl = n - sg.n_begin;
-                float v[4];
+                for (int t = 0; t < TT; ++t) *(f32x4*)(sp + f * fs + t * ts) = acc[f][t];
+        }
+        __syncthreads();
+        const long mbase = m0 + pass * 64;
+        if (!col_orient) {
+            // thread -> fixed 8-column run (col), rows strided by 256 / CPRW: column parameters are loop invariant and
+            // fetched with two 16-byte loads each (bias / gamma buffers are padded to a multiple of 8 floats by the host)
+            constexpr int CPRW = BN / 8, RSTEP = 256 / CPRW;
+            T* __restrict__ out2 = (T*)sg.out2;
+            const T* __restrict__ res = (const T*)sg.res;
+            const int col = (tid % CPRW) * 8, n = n0 + col;
+            if (n < n_end) {
+                const int nl = n - sg.n_begin, cnt = n_end - n < 8 ? n_end - n : 8;
+                float bv[8], gv[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = keep ? acc[f][t][r] : 0.f;
-                    const bool in = n + r < n_end;
-                    if (sg.bias && in) x += sg.bias[nl + r];
-                    x = apply_act(x, sg.act) * sg.scale;
-                    if (sg.gamma && in) x *= sg.gamma[nl + r];
-                    if (res && in) x += to_f32<T>(res[res_row + nl + r]);
-                    v[r] = keep_out ? x : 0.f;
+                for (int e = 0; e < 8; ++e) { bv[e] = 0.f; gv[e] = 1.f; }
+                if (sg.bias) {
+                    const f32x4 b0 = *(const f32x4*)(sg.bias + nl), b1 = *(const f32x4*)(sg.bias + nl + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
                 }
-                long off;
-                if (sg.mode == LWDETR_OUT_HEADS) {
-                    const int h = nl / sg.p1, dd = nl - h * sg.p1;
-                    off = (((long)hb * sg.p2 + h) * sg.p0 + ht) * sg.p1 + dd;
-                } else if (sg.mode == LWDETR_OUT_DECONV2x2) {
-                    const int q4 = nl / sg.p0, co = nl - q4 * sg.p0;
-                    off = (long)tp.b * sg.out_batch_stride +
-                          (sg.out_row_offset + tok_encode(0, 2 * tp.y + (q4 >> 1), 2 * tp.x + (q4 & 1), sg.out_tok)) * sg.ldo + co;
-                } else {
-                    off = rowoff + nl;
+                if (sg.gamma) {
+                    const f32x4 g0 = *(const f32x4*)(sg.gamma + nl), g1 = *(const f32x4*)(sg.gamma + nl + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gv[e] = g0[e]; gv[4 + e] = g1[e]; }
                 }
-                if (n + 3 < n_end && ((off & 3) == 0)) {
-                    V4 o;
+                const long coff = col_offset(sg, nl);
+                const int act = sg.act;
+                const float scale = sg.scale;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
-                    *(V4*)(out + off) = o;
-                    if (out2) *(V4*)(out2 + m * sg.ld2 + nl) = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < n_end) {
-                        out[off + r] = from_f32<T>(v[r]);
-                        if (out2) out2[m * sg.ld2 + nl + r] = from_f32<T>(v[r]);
+                for (int it = 0; it < 64 / RSTEP; ++it) {
+                    const int row = tid / CPRW + it * RSTEP;
+                    const long m = mbase + row;
+                    long roff;
+                    if (m >= d.M || !row_offset(sg, m, roff)) continue;
+                    bool keep_acc = true, keep_out = true;
+                    if (sg.rowmask) {
+                        const bool rm = sg.rowmask[m] != 0;
+                        keep_acc = rm || sg.rowmask_after; keep_out = rm || !sg.rowmask_after;
                     }
+                    float x[8];
+                    {
+                        const f32x4 a0 = *(const f32x4*)(stage + row * SLD + col);
+                        const f32x4 a1 = *(const f32x4*)(stage + row * SLD + col + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { x[e] = keep_acc ? a0[e] : 0.f; x[4 + e] = keep_acc ? a1[e] : 0.f; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += bv[e];
+                    if (act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = act_apply(x[e], act);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = x[e] * scale * gv[e];
+                    if (res) {
+                        const T* rp = res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl;
+                        if (cnt == 8 && ((size_t)rp & 15) == 0) {
+                            const V8 rv = *(const V8*)rp;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(rv[e]);
+                        } else {
+                            for (int e = 0; e < cnt; ++e) x[e] += to_f32<T>(rp[e]);
+                        }
+                    }
+                    if (!keep_out) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+                    }
+                    T* dst = out + roff + coff;
+                    store_run<T, 8>(dst, x, cnt, ((size_t)dst & 15) == 0);
+                    if (out2) { T* d2 = out2 + m * sg.ld2 + nl; store_run<T, 8>(d2, x, cnt, ((size_t)d2 & 15) == 0); }
                 }
             }
-        }
-    } else {
-        // HEADS_T: lane holds rows m..m+3 (tokens) of column n: out[((b*heads+h)*hd+dd)*Tp + t .. t+3]
+        } else {
+            // HEADS_T: out[((b*heads+h)*hd+dd)*Tp + t]: runs of 4 consecutive tokens of one output column
+            constexpr int RPC = 64 / 4;
+#pragma unroll 1
+            for (int c = tid; c < BN * RPC; c += 256) {
+                const int coln = c / RPC, row = (c - coln * RPC) * 4;
+                const long m = mbase + row;
+                const int n = n0 + coln;
+                if (m >= d.M || n >= n_end) continue;
+                const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
+                const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
+                const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                float x[4];
 #pragma unroll
-        for (int f = 0; f < FT; ++f) {
-            const int n = n0 + wn * WN + f * 16 + l15;
-            if (n >= n_end) continue;
-            const int nl = n - sg.n_begin;
-            const float bias = sg.bias ? sg.bias[nl] : 0.f;
-            const int h = nl / sg.p1, dd = nl - h * sg.p1;
-#pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                const long m = m0 + wm * WM + t * 16 + g * 4;
-                if (m >= d.M) continue;
+                for (int e = 0; e < 4; ++e) x[e] = act_apply(a0[e] + bias, sg.act) * sg.scale;
                 const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
-                const long off = (((long)b * sg.p2 + h) * sg.p1 + dd) * sg.p0 + tk;
-                V4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(apply_act(acc[f][t][r] + bias, sg.act) * sg.scale);
-                if (m + 3 < d.M) *(V4*)(out + off) = o;
-                else for (int r = 0; r < 4; ++r) if (m + r < d.M) out[off + r] = o[r];
+                T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
+                store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
             }
         }
+        __syncthreads();
     }
 }
 

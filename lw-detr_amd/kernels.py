@@ -17,6 +17,19 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _pad8(v, n, fill):
+    """The kernels read bias / LayerScale vectors with 16-byte loads in runs of 8: make [0, ceil8(n)) readable."""
+    if v is None:
+        return None
+    assert v.dtype == torch.float32
+    need = (n + 7) // 8 * 8
+    if v.numel() >= need and v.data_ptr() % 16 == 0:
+        return v
+    out = torch.full((need,), fill, dtype=torch.float32, device=v.device)
+    out[:min(n, v.numel())] = v.reshape(-1)[:n]
+    return out
+
+
 def tok_layout(winmajor=False, hp=0, wp=0, twp=0) -> TokLayout:
     return TokLayout(1 if winmajor else 0, hp, wp, twp)
 
@@ -26,10 +39,10 @@ def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE,
         out_batch_stride=0, out_row_offset=0) -> GemmSeg:
     """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h)."""
     s = GemmSeg()
+    bias, gamma = _pad8(bias, n_end - n_begin, 0.0), _pad8(gamma, n_end - n_begin, 1.0)
+    s._keep = (bias, gamma)           # padded copies must outlive the launch
     s.out, s.out2, s.res = _ptr(out), _ptr(out2), _ptr(res)
     s.bias, s.gamma, s.rowmask = _ptr(bias), _ptr(gamma), _ptr(rowmask)
-    for t in (bias, gamma):
-        assert t is None or t.dtype == torch.float32
     assert rowmask is None or rowmask.dtype == torch.uint8
     s.scale, s.act, s.mode, s.n_begin, s.n_end = float(scale), act, mode, n_begin, n_end
     s.ldo, s.ld2, s.ldres, s.res_mod = ldo, ld2, ldres, res_mod
