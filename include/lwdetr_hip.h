@@ -21,6 +21,7 @@
  *                              layout epilogues fused
  *   lwdetr_attention           models/backbone/vit.py:130-137 (window and global softmax(QK^T)V) and
  *                              models/attention.py:563-606 (decoder self-attention)
+ *   lwdetr_mlp_fused           models/backbone/vit.py:217-218 (+ timm.models.layers.Mlp: fc1 -> GELU -> fc2)
  *   lwdetr_layernorm           nn.LayerNorm call sites (vit.py:199,:217; transformer.py:231,:499,:511,:516,:398) and
  *                              the channel LayerNorm of models/backbone/projector.py:21-47
  */
@@ -120,6 +121,17 @@ int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* hip_stream);
 int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* out, long ldo, long M,
                      int C, float eps, long rows_per_batch, long out_batch_rows, long out_row_offset, int dtype,
                      void* hip_stream);
+
+/* ---- fused ViT MLP: x <- x + gamma2 * fc2(GELU(fc1(LN(x)))), one launch, hidden activation stays on chip ---------
+ * Replaces models/backbone/vit.py:217-218 (norm2 -> timm Mlp -> gamma_2 -> residual). Weight packing (host, once):
+ *   w1_folded (4C, C) = fc1.weight * norm2.weight[None, :],  b1_folded = fc1.bias + fc1.weight @ norm2.bias (f32),
+ *   w2_chunked (4C/32, C, 32) = fc2.weight.view(C, 4C/32, 32)[:, :, perm].permute(1, 0, 2): each 32-wide hidden chunk
+ *   contiguous, inside a chunk perm = [4g+e+16*hi for g in 0..3 for hi in 0..1 for e in 0..3] (the kernel's MFMA k-slots).
+ * x is updated in place; out2 (optional, row stride ld2) receives a copy (ViT feature taps); stats_out (optional, (M,2)
+ * f32) receives mean and 1/sqrt(var+eps_next) of the updated rows for the next block's LayerNorm. C in {192, 384}. */
+int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_folded, const void* w2_chunked,
+                     const float* b2, const float* gamma2, void* out2, long ld2, float* stats_out, long M, int C,
+                     float eps, float eps_next, int dtype, void* hip_stream);
 
 /* ---- profiling: per-kernel HIP-event timing on the launch stream (off by default) ------------------------------ */
 int lwdetr_prof_enable(int on);

@@ -22,16 +22,8 @@ namespace {
 constexpr int BK = 32;
 
 // ---- epilogue helpers -------------------------------------------------------------------------------------------
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): GELU stays exact-erf to f32 round-off at a fraction of erff's cost
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.f - poly * __expf(-ax * ax);
-    return x < 0.f ? -e : e;
-}
-__device__ __forceinline__ float act_apply(float x, int act) {
-    if (act == ACT_GELU) return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752440f));
+template <typename T> __device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == ACT_GELU) return gelu_for<T>(x);
     if (act == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
     if (act == ACT_RELU) return x > 0.f ? x : 0.f;
     return x;
@@ -293,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
                     for (int e = 0; e < 8; ++e) x[e] += bv[e];
                     if (act != ACT_NONE) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = act_apply(x[e], act);
+                        for (int e = 0; e < 8; ++e) x[e] = act_apply<T>(x[e], act);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = x[e] * scale * gv[e];
@@ -330,7 +322,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
                 const float bias = sg.bias ? sg.bias[nl] : 0.f;
                 float x[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = act_apply(a0[e] + bias, sg.act) * sg.scale;
+                for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, sg.act) * sg.scale;
                 const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
                 T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
                 store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);

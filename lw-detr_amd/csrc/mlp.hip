@@ -1,0 +1,270 @@
+// Fused transformer MLP for gfx950:  x <- x + gamma2 * ( fc2( GELU( fc1( LN(x) ) ) ) )         (one launch)
+//
+// Replaces, per ViT block, LayerNorm + Linear(C,4C) + GELU + Linear(4C,C) + LayerScale + residual
+// (reference models/backbone/vit.py:217-218 with timm Mlp): the 4C-wide hidden activation never leaves the CU.
+// HBM traffic per block drops from  read x, write LN(x), read LN(x), write h(4C), read h(4C), read x, write x
+// to  read x, write x  (+ weights through L2).
+//
+// Structure (256 threads = 4 waves; each wave owns 16*TT tokens, all four share the weight tiles in LDS):
+//   prologue : wave loads its token rows as MFMA B-operand fragments (lane: token l15, 8 channels per k-chunk) and
+//              normalises them in registers (two-pass f32 statistics; LN's affine is folded into W1/b1 on the host).
+//   hidden loop over chunks of 32 hidden units, double-buffered LDS tiles W1c[32][C] and W2c[C][32] (chunk-major
+//              repacked on the host so every tile is one contiguous 12 KB block), one barrier per chunk:
+//     step 1 : D1[hidden][token] = W1c * LN(x)^T      (A = W1c rows, B = x fragments)         2 x C/32 MFMAs / tile
+//     GELU   : in registers on the accumulator layout (lane: 4 hidden x 1 token)
+//     step 2 : D2[n][token] += W2c[n][hidden] * H      H is ALREADY the B operand: the accumulator layout of step 1
+//              (4 consecutive rows per lane) is the k-run layout of the next MFMA; the implied k-slot permutation
+//              (slots 0-3 <- hidden 4g..4g+3, slots 4-7 <- hidden 16+4g..) is baked into the packed W2 tile.
+//   epilogue : out = x + gamma2 * (D2 + b2), optional second destination (ViT feature taps), and the row statistics
+//              (mean, rstd) of the NEW x for the next block's LayerNorm, which the QKV GEMM applies on load.
+// LDS row strides are == 2 (mod 4) sixteen-byte slots: conflict-free for the 16-lane ds_read_b128 service groups.
+#include "common.h"
+
+#ifndef MLP_WAVES_PER_SIMD
+#define MLP_WAVES_PER_SIMD 2
+#endif
+
+namespace {
+
+struct MlpParams {
+    void* x; long ldx;                 // in/out (M, C)
+    const void* w1; const float* b1;   // (4C, C) with LN gamma folded in, b1' = b1 + W1 beta
+    const void* w2p; const float* b2;  // chunk-major (4C/32, C, 32); (C)
+    const float* gamma2;               // (C) LayerScale
+    void* out2; long ld2;              // optional second destination
+    float* stats_out;                  // optional (M, 2): mean, rstd of the updated rows (eps_next)
+    long M; float eps, eps_next;
+};
+
+template <typename T, int C, int TT>
+__global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpParams p) {
+    typedef typename Vec<T>::v8 V8;
+    typedef typename Vec<T>::v4 V4;
+    constexpr int KC = C / 32;                 // k-chunks of step 1
+    constexpr int NT = C / 16;                 // output tiles of step 2
+    constexpr int HID = 4 * C, NCH = HID / 32; // hidden chunks
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int W1_LD = C + 2 * EPC;         // +32 bytes: row stride == 2 (mod 4) slots for C = 192, 384, 768
+    constexpr int W2_LD = 32 + 2 * EPC;        // +32 bytes: 6 slots (16-bit) / 10 slots (f32) per row, == 2 (mod 4)
+    constexpr int W1_TILE = 32 * W1_LD, W2_TILE = C * W2_LD;
+    constexpr int W1_TILE_PAD = (W1_TILE + 64 * EPC - 1) / (64 * EPC) * (64 * EPC);   // whole 1 KB DMA pieces
+    constexpr int W2_TILE_PAD = (W2_TILE + 64 * EPC - 1) / (64 * EPC) * (64 * EPC);
+    constexpr int TILE_STRIDE = W1_TILE_PAD + W2_TILE_PAD;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = (T*)smem_raw;                    // [2][TILE_STRIDE] weight tiles, then fc1 bias (f32)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long m_wave = (long)blockIdx.x * (64 * TT) + wave * (16 * TT);
+    T* __restrict__ X = (T*)p.x;
+    const T* __restrict__ W1 = (const T*)p.w1;
+    const T* __restrict__ W2 = (const T*)p.w2p;
+
+    // ---- weight tile staging: asynchronous global -> LDS DMA (global_load_lds, 16 B per lane, no staging registers).
+    // The LDS image keeps padded rows (conflict-free fragment reads); a wave-instruction fills 64 consecutive 16-byte
+    // slots, lanes that fall on pad slots fetch a dummy (valid) address. The copies stay in flight across the whole
+    // chunk body and are drained by the chunk-end barrier.
+    constexpr int W1_SLOTS_ROW = W1_LD / EPC, W2_SLOTS_ROW = W2_LD / EPC;
+    constexpr int W1_SLOTS = 32 * W1_SLOTS_ROW, W2_SLOTS = C * W2_SLOTS_ROW;
+    constexpr int W1_INSTR = (W1_SLOTS + 63) / 64, W2_INSTR = (W2_SLOTS + 63) / 64;
+    static_assert(W1_TILE % (64 * EPC) == 0 || true, "");
+    // per-lane source offsets of every DMA piece this wave issues (chunk invariant; -1 = pad slot)
+    constexpr int W1_MY = (W1_INSTR + 3) / 4, W2_MY = (W2_INSTR + 3) / 4;
+    int off1[W1_MY], off2[W2_MY];
+#pragma unroll
+    for (int k = 0; k < W1_MY; ++k) {
+        const int slot = (wave + 4 * k) * 64 + lane, row = slot / W1_SLOTS_ROW, c = slot - row * W1_SLOTS_ROW;
+        off1[k] = (row < 32 && c < C / EPC) ? row * C + c * EPC : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < W2_MY; ++k) {
+        const int slot = (wave + 4 * k) * 64 + lane, row = slot / W2_SLOTS_ROW, c = slot - row * W2_SLOTS_ROW;
+        off2[k] = (row < C && c < 32 / EPC) ? row * 32 + c * EPC : 0;
+    }
+    auto stage_w = [&](int hc, int buf) {
+        T* w1s = smem + buf * TILE_STRIDE;
+        T* w2s = w1s + W1_TILE_PAD;
+        const T* s1 = W1 + (long)hc * 32 * C;
+        const T* s2 = W2 + (long)hc * 32 * C;
+#pragma unroll
+        for (int k = 0; k < W1_MY; ++k) {
+            const int i = wave + 4 * k;
+            if (i < W1_INSTR)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + off1[k]),
+                                                 (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < W2_MY; ++k) {
+            const int i = wave + 4 * k;
+            if (i < W2_INSTR)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s2 + off2[k]),
+                                                 (__attribute__((address_space(3))) void*)(w2s + i * 64 * EPC), 16, 0, 0);
+        }
+    };
+    stage_w(0, 0);
+    // fc1 bias -> LDS once (ordinary global loads inside the loop would force an early drain of the DMA queue)
+    float* b1s = (float*)(smem + 2 * TILE_STRIDE);
+    for (int i = tid; i < HID; i += 256) b1s[i] = p.b1[i];
+
+    // ---- prologue: token rows -> normalised B-operand fragments
+    V8 xf[TT][KC];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        long m = m_wave + t * 16 + l15; m = m < p.M ? m : p.M - 1;
+        const T* xr = X + m * p.ldx + g * 8;
+        float s = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            xf[t][kc] = *(const V8*)(xr + kc * 32);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += to_f32<T>(xf[t][kc][e]);
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s * (1.f / C);
+        float v = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = to_f32<T>(xf[t][kc][e]) - mean; v += dl * dl; }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[t][kc][e] = from_f32<T>((to_f32<T>(xf[t][kc][e]) - mean) * rstd);
+    }
+
+    f32x4 acc2[NT][TT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc2[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+    for (int hc = 0; hc < NCH; ++hc) {
+        const int buf = hc & 1;
+        if (hc + 1 < NCH) stage_w(hc + 1, buf ^ 1);
+        const T* w1s = smem + buf * TILE_STRIDE;
+        const T* w2s = w1s + W1_TILE_PAD;
+        // bias of this lane's 8 hidden units: rows 4g..4g+3 of the two 16-row tiles
+        const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
+        // ---- step 1
+        f32x4 acc1[2][TT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc1[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const V8 a = *(const V8*)(w1s + (h * 16 + l15) * W1_LD + kc * 32 + g * 8);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc1[h][t] = Mma<T>::k32(a, xf[t][kc], acc1[h][t]);
+            }
+        }
+        // ---- GELU on the accumulator layout -> B operand of step 2
+        V8 hf[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hf[t][e] = from_f32<T>(gelu_for<T>(acc1[0][t][e] + bia0[e]));
+                hf[t][4 + e] = from_f32<T>(gelu_for<T>(acc1[1][t][e] + bia1[e]));
+            }
+        // ---- step 2
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const V8 a = *(const V8*)(w2s + (n * 16 + l15) * W2_LD + g * 8);   // k-slot order pre-permuted on the host
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc2[n][t] = Mma<T>::k32(a, hf[t], acc2[n][t]);
+        }
+        __syncthreads();        // drains this chunk's DMA (vmcnt) and orders the buffer swap
+    }
+
+    // ---- epilogue: lane holds channels n*16 + 4g .. +3 of token l15
+    T* __restrict__ O2 = (T*)p.out2;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const long m = m_wave + t * 16 + l15;
+        const bool ok = m < p.M;
+        const long mr = ok ? m : p.M - 1;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int c0 = n * 16 + g * 4;
+            const f32x4 b2 = *(const f32x4*)(p.b2 + c0), g2 = *(const f32x4*)(p.gamma2 + c0);
+            const f32x4 xr = up4<T>(*(const V4*)(X + mr * p.ldx + c0));
+            // round to the storage type now: the statistics below describe exactly what the next LayerNorm reads
+            acc2[n][t] = up4<T>(cvt4<T>(xr + g2 * (acc2[n][t] + b2)));
+        }
+        if (p.stats_out) {
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) s += acc2[n][t][0] + acc2[n][t][1] + acc2[n][t][2] + acc2[n][t][3];
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            const float mean = s * (1.f / C);
+            float v = 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dl = acc2[n][t][e] - mean; v += dl * dl; }
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (ok && g == 0) { p.stats_out[2 * m] = mean; p.stats_out[2 * m + 1] = 1.f / sqrtf(v * (1.f / C) + p.eps_next); }
+        }
+        if (ok) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const V4 o = cvt4<T>(acc2[n][t]);
+                *(V4*)(X + m * p.ldx + n * 16 + g * 4) = o;
+                if (O2) *(V4*)(O2 + m * p.ld2 + n * 16 + g * 4) = o;
+            }
+        }
+    }
+}
+
+template <typename T, int C, int TT>
+int launch_mlp(const MlpParams& p, hipStream_t st) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int PIECE = 64 * EPC;
+    constexpr int W1P = (32 * (C + 2 * EPC) + PIECE - 1) / PIECE * PIECE, W2P = (C * (32 + 2 * EPC) + PIECE - 1) / PIECE * PIECE;
+    constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 4 * C * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const long blocks = (p.M + 64 * TT - 1) / (64 * TT);
+    ProfScope ps(KID_MLP, 16.0 * p.M * C * C, (double)p.M * C * sizeof(T) * 2 + 8.0 * C * C * sizeof(T), st);
+    hipLaunchKernelGGL((mlp_kernel<T, C, TT>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    return lwdetr_check_launch();
+}
+
+template <typename T, int TT16, int TT32>
+int dispatch_c(const MlpParams& p, int C, hipStream_t st) {
+    switch (C) {
+        case 192: return launch_mlp<T, 192, TT16>(p, st);
+        case 384: return launch_mlp<T, 384, TT32>(p, st);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_folded, const void* w2_chunked,
+                                const float* b2, const float* gamma2, void* out2, long ld2, float* stats_out, long M,
+                                int C, float eps, float eps_next, int dtype, void* hip_stream) {
+    if (!x || !w1_folded || !b1_folded || !w2_chunked || !b2 || !gamma2 || M < 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    if (ldx % 8 != 0 || (out2 && ld2 % 8 != 0)) return LWDETR_ERR_BAD_ARG;
+    MlpParams p;
+    p.x = x; p.ldx = ldx; p.w1 = w1_folded; p.b1 = b1_folded; p.w2p = w2_chunked; p.b2 = b2; p.gamma2 = gamma2;
+    p.out2 = out2; p.ld2 = ld2; p.stats_out = stats_out; p.M = M; p.eps = eps; p.eps_next = eps_next;
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (dtype) {
+        case DT_F16: return dispatch_c<f16, 2, 1>(p, C, st);
+        case DT_BF16: return dispatch_c<bf16, 2, 1>(p, C, st);
+        case DT_F32: return dispatch_c<float, 1, 1>(p, C, st);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}

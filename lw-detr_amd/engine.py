@@ -60,6 +60,13 @@ class PackedWeights:
             self._cache[ck] = builder().to(device=self.device, dtype=dtype or self.dtype).contiguous()
         return self._cache[ck]
 
+    def custom_multi(self, name, builder):
+        """Like ``custom`` for builders returning a tuple of tensors that already carry their final dtype."""
+        ck = ("m", name)
+        if ck not in self._cache:
+            self._cache[ck] = tuple(t.to(device=self.device).contiguous() for t in builder())
+        return self._cache[ck]
+
     # ---- conv + eval-BatchNorm folding (reference ConvX: conv(bias=False) -> BN -> act, projector.py:85-98)
     def convx(self, prefix):
         ck = ("convx", prefix)
@@ -156,7 +163,8 @@ class ForwardPlan:
         pre = "backbone.0.encoder"
         self.images = z(B, 3, self.H, self.W)
         self.x = z(rows, C)
-        xn, att, hid = z(rows, C), z(rows, C), z(rows, 4 * C)
+        xn, att = z(rows, C), z(rows, C)
+        hid = None if K.mlp_fused_supported(C, self.T) else z(rows, 4 * C)
         q, k, vt = z(B, heads, Tp, hd), z(B, heads, Tp, hd), z(B, heads, hd, Tp)
         ntap = len(self.taps)
         self.taps_cat = z(rows, ntap * C)
@@ -185,16 +193,23 @@ class ForwardPlan:
             ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
                 seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
                     res=self.x, ldres=C)]))
-            ops.append(LayerNormOp(self.x, pw.f(blk + ".norm2.weight"), pw.f(blk + ".norm2.bias"), xn, rows, C, 1e-6))
-            ops.append(GemmOp(xn, pw.w(blk + ".mlp.fc1.weight"), rows, 4 * C, C, [
-                seg(hid, 0, 4 * C, ldo=4 * C, bias=pw.f(blk + ".mlp.fc1.bias"), act=ACT_GELU)]))
             tap_out = None
             if i in self.taps:
                 j = self.taps.index(i)
                 tap_out = self.taps_cat[:, j * C:]
-            ops.append(GemmOp(hid, pw.w(blk + ".mlp.fc2.weight"), rows, C, 4 * C, [
-                seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".mlp.fc2.bias"), gamma=pw.f(blk + ".gamma_2"), res=self.x,
-                    ldres=C, out2=tap_out, ld2=ntap * C)], keep=(tap_out,)))
+            if K.mlp_fused_supported(C, self.T):
+                w1f, b1f, w2c = pw.custom_multi(blk + ".mlp.packed", lambda blk=blk: K.pack_mlp_weights(
+                    pw.sd[blk + ".mlp.fc1.weight"], pw.sd[blk + ".mlp.fc1.bias"], pw.sd[blk + ".mlp.fc2.weight"],
+                    pw.sd[blk + ".norm2.weight"], pw.sd[blk + ".norm2.bias"], self.T))
+                ops.append(K.MlpFusedOp(self.x, w1f, b1f, w2c, pw.f(blk + ".mlp.fc2.bias"), pw.f(blk + ".gamma_2"), rows,
+                                        C, 1e-6, out2=tap_out, ld2=ntap * C))
+            else:
+                ops.append(LayerNormOp(self.x, pw.f(blk + ".norm2.weight"), pw.f(blk + ".norm2.bias"), xn, rows, C, 1e-6))
+                ops.append(GemmOp(xn, pw.w(blk + ".mlp.fc1.weight"), rows, 4 * C, C, [
+                    seg(hid, 0, 4 * C, ldo=4 * C, bias=pw.f(blk + ".mlp.fc1.bias"), act=ACT_GELU)]))
+                ops.append(GemmOp(hid, pw.w(blk + ".mlp.fc2.weight"), rows, C, 4 * C, [
+                    seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".mlp.fc2.bias"), gamma=pw.f(blk + ".gamma_2"), res=self.x,
+                        ldres=C, out2=tap_out, ld2=ntap * C)], keep=(tap_out,)))
 
     # ------------------------------------------------------------------------------------------ projector
     def _convx_1x1(self, prefix, A, lda, M, cin, out_seg_fn, a_ptr_off=0):

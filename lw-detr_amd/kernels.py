@@ -118,6 +118,43 @@ class LayerNormOp:
             _nat.check(rc, "layernorm")
 
 
+def mlp_fused_supported(C_, dtype) -> bool:
+    """Shapes the fused MLP kernel is instantiated for (LDS / register budget): C=192 any dtype, C=384 16-bit."""
+    return C_ == 192 or (C_ == 384 and dtype in (torch.float16, torch.bfloat16))
+
+
+def pack_mlp_weights(w1, b1, w2, ln_w, ln_b, dtype):
+    """Host-side packing for lwdetr_mlp_fused (f32 master tensors in, device tensors of ``dtype`` / f32 out):
+    LayerNorm's affine is folded into fc1, fc2 is re-laid out chunk-major (32 hidden units per contiguous tile)."""
+    w1, b1, w2, ln_w, ln_b = (t.float() for t in (w1, b1, w2, ln_w, ln_b))
+    c = w1.shape[1]
+    w1f = (w1 * ln_w[None, :]).to(dtype).contiguous()
+    b1f = (b1 + w1 @ ln_b).contiguous()
+    # chunk-major, and inside a chunk the MFMA k-slot order of the fused kernel: lane group g holds hidden
+    # (4g..4g+3, 16+4g..16+4g+3) as one contiguous run of 8
+    perm = torch.tensor([4 * g_ + e + 16 * hi for g_ in range(4) for hi in range(2) for e in range(4)])
+    w2c = w2.view(c, (4 * c) // 32, 32)[:, :, perm].permute(1, 0, 2).to(dtype).contiguous()
+    return w1f, b1f, w2c
+
+
+class MlpFusedOp:
+    """x <- x + gamma2 * fc2(GELU(fc1(LN(x)))) in one launch (weights packed by ``pack_mlp_weights``)."""
+
+    def __init__(self, x, w1f, b1f, w2c, b2, gamma2, M, C_, eps, *, ldx=None, out2=None, ld2=0, stats_out=None,
+                 eps_next=1e-6):
+        assert b1f.dtype == torch.float32 and b2.dtype == torch.float32 and gamma2.dtype == torch.float32
+        assert w1f.dtype == x.dtype and w2c.dtype == x.dtype and w1f.is_contiguous() and w2c.is_contiguous()
+        self.args = (_ptr(x), ldx if ldx is not None else C_, _ptr(w1f), _ptr(b1f), _ptr(w2c), _ptr(b2), _ptr(gamma2),
+                     _ptr(out2), ld2, _ptr(stats_out), M, C_, float(eps), float(eps_next), _nat.dtype_code(x.dtype))
+        self._keep = (x, w1f, b1f, w2c, b2, gamma2, out2, stats_out)
+        self._fn = _nat.lib().lwdetr_mlp_fused
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "mlp_fused")
+
+
 class MsdaFusedOp:
     def __init__(self, value, shapes, lsi, oa, ld_oa, logit_col, ref, vr, out, *, B, S, M, D, L, Q, P):
         assert ref.dtype == torch.float32 and vr.dtype == torch.float32

@@ -219,6 +219,32 @@ def test_layernorm(dtype, c):
     assert (ob.reshape(2, s_total, c)[:, off:off + rows].float() - refb).abs().max().item() < 6e-2
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,m", [(192, 1000), (192, 64), (384, 333)])
+def test_mlp_fused(dtype, c, m):
+    """LN -> fc1 -> GELU -> fc2 -> LayerScale -> residual in one launch vs the unfused torch fp32 formulation."""
+    from lwdetr_amd import kernels as K
+    if not K.mlp_fused_supported(c, dtype):
+        pytest.skip("not instantiated for this shape / dtype")
+    x = _rand(m, c, dtype=dtype, seed=1) * 2 + 0.3
+    w1, b1 = _rand(4 * c, c, scale=c ** -0.5, seed=2), _rand(4 * c, seed=3) * 0.1
+    w2, b2 = _rand(c, 4 * c, scale=(4 * c) ** -0.5, seed=4), _rand(c, seed=5) * 0.1
+    lw, lb, g2 = _rand(c, seed=6) * 0.2 + 1, _rand(c, seed=7) * 0.1, _rand(c, seed=8) * 0.3
+    xf = x.float()
+    ref = xf + g2 * (F.gelu(F.layer_norm(xf, (c,), lw, lb, 1e-6) @ w1.t() + b1) @ w2.t() + b2)
+    w1f, b1f, w2c = K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype)
+    out2 = torch.zeros(m, 2 * c, dtype=dtype, device=_dev())
+    stats = torch.zeros(m, 2, device=_dev())
+    xx = x.clone()
+    K.MlpFusedOp(xx, w1f, b1f, w2c, b2, g2, m, c, 1e-6, out2=out2[:, c:], ld2=2 * c, stats_out=stats, eps_next=1e-6)()
+    tol = {torch.float32: 3e-5, torch.float16: 6e-3, torch.bfloat16: 5e-2}[dtype]
+    assert _relerr(xx, ref) < tol, _relerr(xx, ref)
+    assert torch.equal(out2[:, c:], xx) and out2[:, :c].abs().max().item() == 0
+    mean, var = xx.float().mean(1), xx.float().var(1, unbiased=False)
+    assert (stats[:, 0] - mean).abs().max().item() < 1e-4
+    assert ((stats[:, 1] - (var + 1e-6).rsqrt()).abs() / (var + 1e-6).rsqrt()).max().item() < 1e-4
+
+
 def test_gemm_rejects_bad_arguments():
     from lwdetr_amd import kernels as K
     from lwdetr_amd._native import NativeError

@@ -78,5 +78,21 @@ def main():
     print(f"device copy 256 MiB: {us:8.1f} us = {2 * big.numel() / us / 1e3:7.1f} GB/s")
 
 
+def bench_mlp(batch=32, C=192, dtype=torch.float16):
+    dev = "cuda:0"
+    M = batch * 1600
+    x = torch.randn(M, C, device=dev).to(dtype)
+    w1, b1 = torch.randn(4 * C, C) * C ** -0.5, torch.randn(4 * C) * 0.1
+    w2, b2 = torch.randn(C, 4 * C) * (4 * C) ** -0.5, torch.randn(C, device=dev) * 0.1
+    lw, lb, g2 = torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.rand(C, device=dev) * 0.3
+    w1f, b1f, w2c = (t.to(dev) for t in K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype))
+    op = K.MlpFusedOp(x, w1f, b1f, w2c, b2, g2, M, C, 1e-6)
+    us = timeit(op)
+    print(f"mlp_fused C={C}: {us:8.1f} us  {16.0 * M * C * C / us / 1e6:7.1f} TFLOP/s")
+
+
 if __name__ == "__main__":
     main()
+    bench_mlp()
+
+
