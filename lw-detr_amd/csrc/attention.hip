@@ -17,8 +17,27 @@
 // V^T operand by loading two 8-byte runs per lane. Waves are independent (no LDS, no barriers): K / V^T tiles are
 // re-read through L1/L2, which holds a whole (image, head) slice (1600 x 16 x 2 B x 2 = 100 KB at 640x640).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
+
+// cross-row reductions on the VALU (v_permlane16_swap / v_permlane32_swap) instead of ds_bpermute through the LDS
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <typename T, int HD, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
@@ -53,103 +72,137 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
         }
     }
 
-    f32x4 o[QT][DT];
-    float m_run[QT], l_run[QT];
+    // Accumulators: O^T tiles, and the softmax denominator as one extra MFMA against an all-ones A operand (every
+    // register of lsum[t] then holds the full row sum of query l15: no VALU adds, no cross-lane reduction).
+    f32x4 o[QT][DT], lsum[QT];
+    float m_run[QT];            // exponent reference of each query (log2 domain); scores enter the MFMA as C = -m_run
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m_run[t] = -INFINITY; l_run[t] = 0.f;
+        m_run[t] = 0.f; lsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    V8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = from_f32<T>(1.f);
 
     const bool holes = p.sub_len < p.sub_stride;
-    for (int k0 = 0; k0 < nkeys; k0 += 32) {
-        // ---- S^T tiles: s[t][kt][r] = score(key k0 + kt*16 + g*4 + r, query q0 + t*16 + l15)
-        f32x4 s[QT][2];
+    constexpr float RESCALE_THR = 8.f;      // lazy rescaling: keep the old reference while no score exceeds it by 2^8
+
+    // K / V^T operand fragments of one 32-key step; loaded one step ahead (software pipelining: the loads of step i+1
+    // are in flight while step i runs its MFMAs and exps)
+    struct KV { V8 k8[2][NC]; V4 k4[2]; V8 v[DT]; };
+    auto load_kv = [&](int k0, KV& f) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             int key = k0 + kt * 16 + l15; key = key < last ? key : last;
             if (HD >= 32) {
-                V8 kf[NC];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) kf[c] = *(const V8*)(Kb + (long)key * HD + c * 32 + g * 8);
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) a = Mma<T>::k32(kf[c], q8[t][c], a);
-                    s[t][kt] = a;
-                }
+                for (int c = 0; c < NC; ++c) f.k8[kt][c] = *(const V8*)(Kb + (long)key * HD + c * 32 + g * 8);
             } else {
-                const V4 kf = *(const V4*)(Kb + (long)key * HD + g * 4);
-#pragma unroll
-                for (int t = 0; t < QT; ++t) s[t][kt] = Mma<T>::k16(kf, q4[t], f32x4{0.f, 0.f, 0.f, 0.f});
+                f.k4[kt] = *(const V4*)(Kb + (long)key * HD + g * 4);
             }
         }
-        // ---- mask keys beyond the sequence / pad rows inside it
+        // V^T (A operand of O^T = V^T P^T): k-slots 0..3 <- keys k0+4g.., slots 4..7 <- keys k0+16+4g..
+        int ka = k0 + g * 4, kb = k0 + 16 + g * 4;
+        ka = ka + 3 < nkeys ? ka : (nkeys - 4);
+        kb = kb + 3 < nkeys ? kb : (nkeys - 4);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const T* vrow = Vb + (long)(dt * 16 + l15) * p.Tp;
+            const V4 lo = *(const V4*)(vrow + ka), hi = *(const V4*)(vrow + kb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f.v[dt][e] = lo[e]; f.v[dt][4 + e] = hi[e]; }
+        }
+    };
+
+    auto step = [&](const KV& f, int k0) {
+        // ---- S'^T tiles: s[t][kt][r] = score(key k0 + kt*16 + 4g + r, query q0 + t*16 + l15) - m_run[t]
+        f32x4 s[QT][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const float nm = -m_run[t];
+                f32x4 a = {nm, nm, nm, nm};
+                if (HD >= 32) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) a = Mma<T>::k32(f.k8[kt][c], q8[t][c], a);
+                } else {
+                    a = Mma<T>::k16(f.k4[kt], q4[t], a);
+                }
+                s[t][kt] = a;
+            }
+        }
+        // ---- mask keys beyond the sequence / pad rows inside it (plain selects: a nested-branch formulation of this
+        // block was miscompiled by hipcc 7.2 - the inner condition's select got dropped)
         if (k0 + 32 > nkeys || holes) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = k0 + kt * 16 + g * 4 + r;
-                    const bool ok = key < nkeys && (!holes || (key % p.sub_stride) < p.sub_len);
-                    if (!ok) {
+                    const int sub = holes ? key % p.sub_stride : 0;
+                    const bool ok = (key < nkeys) & (sub < p.sub_len);
 #pragma unroll
-                        for (int t = 0; t < QT; ++t) s[t][kt][r] = -INFINITY;
-                    }
+                    for (int t = 0; t < QT; ++t) s[t][kt][r] = ok ? s[t][kt][r] : -INFINITY;
                 }
         }
-        // ---- V^T fragments (A operand of O^T = V^T P^T): k-slots 0..3 <- keys k0+4g.., slots 4..7 <- keys k0+16+4g..
-        V8 vf[DT];
-        {
-            int ka = k0 + g * 4, kb = k0 + 16 + g * 4;
-            ka = ka + 3 < nkeys ? ka : (nkeys - 4);
-            kb = kb + 3 < nkeys ? kb : (nkeys - 4);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const T* vrow = Vb + (long)(dt * 16 + l15) * p.Tp;
-                const V4 lo = *(const V4*)(vrow + ka), hi = *(const V4*)(vrow + kb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[dt][e] = lo[e]; vf[dt][4 + e] = hi[e]; }
-            }
-        }
-        // ---- online softmax (log2 domain) + P V
+        // ---- lazy online softmax: the reference only moves when some score exceeds it by more than RESCALE_THR
+        // (always on the first step). Everything at the old reference - O, the denominator - is rescaled exactly once.
+        float lmax[QT];
+        bool need = k0 == 0;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = fmaxf(fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3])),
-                             fmaxf(fmaxf(s[t][1][0], s[t][1][1]), fmaxf(s[t][1][2], s[t][1][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[t], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
-            m_run[t] = m_new;
+            lmax[t] = fmaxf(fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3])),
+                            fmaxf(fmaxf(s[t][1][0], s[t][1][1]), fmaxf(s[t][1][2], s[t][1][3])));
+            need = need || lmax[t] > RESCALE_THR;
+        }
+        if (__any(need)) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                float mx = xor32_max(xor16_max(lmax[t]));           // row max relative to the current reference
+                mx = k0 == 0 ? mx : fmaxf(mx, 0.f);                 // the reference never decreases after step 0
+                const float alpha = __builtin_amdgcn_exp2f(-mx);
+                m_run[t] += mx;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) s[t][kt] -= mx;
+                lsum[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[t][dt] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
             V8 pf;
-            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[t][kt][r] - m_new);
-                    psum += pv;
-                    pf[kt * 4 + r] = from_f32<T>(pv);
-                }
-            l_run[t] = l_run[t] * alpha + psum;
+                for (int r = 0; r < 4; ++r) pf[kt * 4 + r] = from_f32<T>(__builtin_amdgcn_exp2f(s[t][kt][r]));
+            lsum[t] = Mma<T>::k32(ones, pf, lsum[t]);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                o[t][dt] *= alpha;
-                o[t][dt] = Mma<T>::k32(vf[dt], pf, o[t][dt]);
-            }
+            for (int dt = 0; dt < DT; ++dt) o[t][dt] = Mma<T>::k32(f.v[dt], pf, o[t][dt]);
         }
+    };
+
+    KV fa, fb;
+    load_kv(0, fa);
+    for (int k0 = 0;;) {
+        if (k0 + 32 < nkeys) load_kv(k0 + 32, fb);
+        step(fa, k0);
+        k0 += 32;
+        if (k0 >= nkeys) break;
+        if (k0 + 32 < nkeys) load_kv(k0 + 32, fa);
+        step(fb, k0);
+        k0 += 32;
+        if (k0 >= nkeys) break;
     }
 
     // ---- normalise and store: lane holds channels dt*16 + 4g .. +3 of query q0 + t*16 + l15
     T* __restrict__ out = (T*)p.out;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        float l = l_run[t];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = lsum[t][0];
         const float inv = 1.f / l;
         const int q = q0 + t * 16 + l15;
         if (q < nkeys) {
@@ -165,9 +218,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     }
 }
 
-template <typename T, int HD>
-int launch(const lwdetr_attn_desc& p, hipStream_t st) {
-    constexpr int QT = 2;
+template <typename T, int HD, int QT>
+int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
     const int units = (p.keys_per_seq + 16 * QT - 1) / (16 * QT);
     dim3 grid((units + 3) / 4, p.heads, p.B * p.seqs_per_img);
     const double nseq = (double)p.B * p.seqs_per_img;
@@ -177,6 +229,16 @@ int launch(const lwdetr_attn_desc& p, hipStream_t st) {
     ProfScope ps(kid, flops, bytes, st);
     hipLaunchKernelGGL((attn_kernel<T, HD, QT>), grid, dim3(256), 0, st, p);
     return lwdetr_check_launch();
+}
+
+template <typename T, int HD>
+int launch(const lwdetr_attn_desc& p, hipStream_t st) {
+    // long sequences: 64 queries per wave (K / V^T fragments amortised over 4 query tiles); short ones keep 32 so a
+    // 100-token window still spreads over 4 waves
+    static const char* force = getenv("LWDETR_ATTN_QT");
+    const bool qt4 = force ? atoi(force) == 4 : (p.keys_per_seq >= 1024 && HD <= 32 && sizeof(T) == 2);
+    if (qt4) return launch_qt<T, HD, (HD <= 32 ? 4 : 2)>(p, st);
+    return launch_qt<T, HD, 2>(p, st);
 }
 
 template <typename T>

@@ -68,7 +68,8 @@ template <typename T, int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
     constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     constexpr int CPR = BK / EPC;              // chunks per tile row
-    constexpr int LDS_LD = BK + EPC;           // padded LDS row (elements)
+    constexpr int LDS_LD = BK + 2 * EPC;       // +32 B: row stride 6 (16-bit) / 10 (f32) sixteen-byte slots, == 2 (mod 4):
+                                               // conflict-free for the 16-lane ds_read_b128 service groups
     constexpr int RPP = 256 / CPR;             // tile rows covered by one pass of the 256 threads
     constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
     constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
@@ -227,9 +228,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
     constexpr int SLD = BN + 4, SLD_T = 64 + 4;
     const int n_end = sg.n_end < d.N ? sg.n_end : d.N;
     T* __restrict__ out = (T*)sg.out;
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wm == pass) {
-            float* sp = col_orient ? stage + (wn * WN + l15) * SLD_T + g * 4 : stage + l15 * SLD + wn * WN + g * 4;
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        if (BM == 64 || wm == pass) {
+            const int r0 = BM == 64 ? wm * WM : 0;          // first stage row of this wave
+            float* sp = col_orient ? stage + (wn * WN + l15) * SLD_T + r0 + g * 4 : stage + (r0 + l15) * SLD + wn * WN + g * 4;
             const int fs = col_orient ? 16 * SLD_T : 16, ts = col_orient ? 16 : 16 * SLD;
 #pragma unroll
             for (int f = 0; f < FT; ++f)
@@ -341,12 +343,17 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     const int BNsel = bn64 ? 64 : 128;
     for (int s = 0; s < d.nseg; ++s)
         if (d.seg[s].n_begin % BNsel != 0) return LWDETR_ERR_UNSUPPORTED;
-    const long tiles_m = (d.M + 127) / 128, tiles_n = (d.N + BNsel - 1) / BNsel;
+    long tiles_m = (d.M + 127) / 128, tiles_n = (d.N + BNsel - 1) / BNsel;
+    // small problems (decoder / head GEMMs: a few thousand rows) would leave most of the 256 CUs idle with 128-row
+    // tiles: switch to 64 x 64 tiles when the 128-row grid has fewer than ~1.5 workgroups per CU
+    const bool small = tiles_m * tiles_n < 384;
+    if (small) { tiles_m = (d.M + 63) / 64; tiles_n = (d.N + 63) / 64; }
     const long nwg = tiles_m * tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
     const int kid = AMODE == LWDETR_A_PLAIN ? KID_GEMM : (AMODE == LWDETR_A_CONV3x3 ? KID_GEMM_CONV : KID_GEMM_PATCH);
     ProfScope ps(kid, 2.0 * d.M * d.N * d.K, ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) * sizeof(T), st);
-    if (bn64) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+    if (small) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+    else if (bn64) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
     else if constexpr (sizeof(T) == 2)
         hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
     return lwdetr_check_launch();
