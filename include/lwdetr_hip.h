@@ -133,6 +133,19 @@ int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_f
                      const float* b2, const float* gamma2, void* out2, long ld2, float* stats_out, long M, int C,
                      float eps, float eps_next, int dtype, void* hip_stream);
 
+/* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
+ * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */
+int lwdetr_select_gather(const void* om, const void* enc_cls, long ldc, const float* props, const int64_t* idx,
+                         void* om_sel, void* logits_out, float* props_sel, int B, int S, int d, int nq, int ncls,
+                         int dtype, void* hip_stream);
+/* enc_delta (B*nq,4): bbox-MLP output of the selected rows; writes enc boxes (B,nq,4), decoder reference boxes ref_out
+ * (B,nq,4) f32, the (y,x,w,h) sine embedding of ref * valid_ratio[level 0] (B*nq, 2d) and the broadcast queries (B*nq, d). */
+int lwdetr_decoder_inputs(const void* enc_delta, const float* props_sel, const float* refpoint, const float* valid_ratios,
+                          int L, const void* query_feat, const float* dim_t, void* enc_boxes_out, float* ref_out,
+                          void* sine_out, void* xdec_out, int B, int nq, int d, int dtype, void* hip_stream);
+/* out[r] = (delta_xy * ref_wh + ref_xy, exp(delta_wh) * ref_wh) with ref row r % ref_rows (no sigmoid: bbox_reparam). */
+int lwdetr_box_reparam(const void* delta, const float* ref, long ref_rows, void* out, long R, int dtype, void* hip_stream);
+
 /* ---- profiling: per-kernel HIP-event timing on the launch stream (off by default) ------------------------------ */
 int lwdetr_prof_enable(int on);
 int lwdetr_prof_num_kernels(void);

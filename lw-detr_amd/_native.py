@@ -72,13 +72,17 @@ def lib():
         l.lwdetr_attention.argtypes = [C.POINTER(AttnDesc), i, vp]
         l.lwdetr_layernorm.argtypes = [vp, lg, vp, vp, vp, lg, lg, i, f, lg, lg, lg, i, vp]
         l.lwdetr_mlp_fused.argtypes = [vp, lg, vp, vp, vp, vp, vp, vp, lg, vp, lg, i, f, f, i, vp]
+        l.lwdetr_select_gather.argtypes = [vp, vp, lg, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+        l.lwdetr_decoder_inputs.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
+        l.lwdetr_box_reparam.argtypes = [vp, vp, lg, vp, lg, i, vp]
         l.lwdetr_prof_enable.argtypes = [i]
         l.lwdetr_prof_num_kernels.argtypes = []
         l.lwdetr_prof_kernel_name.argtypes = [i]
         l.lwdetr_prof_kernel_name.restype = C.c_char_p
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
         for fn in ("lwdetr_msda_forward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
-                   "lwdetr_layernorm", "lwdetr_mlp_fused", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
+                   "lwdetr_layernorm", "lwdetr_mlp_fused", "lwdetr_select_gather", "lwdetr_decoder_inputs",
+                   "lwdetr_box_reparam", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int
         _lib = l
     return _lib

@@ -100,3 +100,110 @@ extern "C" int lwdetr_layernorm(const void* x, long ldx, const float* gamma, con
         default: return LWDETR_ERR_UNSUPPORTED;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small fused glue kernels of the two-stage selection / decoder set-up (each replaces a dozen tiny tensor ops):
+//   select_gather   : rows picked by the two-stage top-k -> encoder features, their class logits, their anchor proposals
+//                     (reference models/transformer.py:248-255, models/lwdetr.py:168-170)
+//   decoder_inputs  : box re-parameterisation of the selected proposals and of the learned reference points
+//                     (transformer.py:236-240, :266-274), sine embedding of the references (transformer.py:42-68, order
+//                     y,x,w,h, applied to ref * valid_ratio of level 0, :352-355) and the query broadcast (:266)
+//   box_reparam     : final boxes of all decoder layers (models/lwdetr.py:150-155)
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void select_gather_kernel(const T* __restrict__ om, const T* __restrict__ enc_cls, long ldc,
+                                                            const float* __restrict__ props, const int64_t* __restrict__ idx,
+                                                            T* __restrict__ om_sel, T* __restrict__ logits_out,
+                                                            float* __restrict__ props_sel, int B, int S, int d, int nq, int ncls) {
+    const long row = blockIdx.x;                       // b * nq + q
+    const int b = (int)(row / nq);
+    const long src = (long)b * S + idx[row];
+    for (int c = threadIdx.x; c < d; c += blockDim.x) om_sel[row * d + c] = om[src * d + c];
+    for (int c = threadIdx.x; c < ncls; c += blockDim.x) logits_out[row * ncls + c] = enc_cls[src * ldc + c];
+    if (threadIdx.x < 4) props_sel[row * 4 + threadIdx.x] = props[src * 4 + threadIdx.x];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decoder_inputs_kernel(const T* __restrict__ enc_delta, const float* __restrict__ props_sel,
+                                                             const float* __restrict__ refpoint, const float* __restrict__ vr,
+                                                             int L, const T* __restrict__ query_feat,
+                                                             const float* __restrict__ dim_t, T* __restrict__ enc_boxes,
+                                                             float* __restrict__ ref_out, T* __restrict__ sine,
+                                                             T* __restrict__ xdec, int B, int nq, int d) {
+    const long row = blockIdx.x;
+    const int b = (int)(row / nq), q = (int)(row - (long)b * nq);
+    float dl[4], pr[4], ts[4], rp[4], rf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dl[i] = to_f32<T>(enc_delta[row * 4 + i]); pr[i] = props_sel[row * 4 + i]; rp[i] = refpoint[q * 4 + i]; }
+    ts[0] = dl[0] * pr[2] + pr[0]; ts[1] = dl[1] * pr[3] + pr[1]; ts[2] = expf(dl[2]) * pr[2]; ts[3] = expf(dl[3]) * pr[3];
+    rf[0] = rp[0] * ts[2] + ts[0]; rf[1] = rp[1] * ts[3] + ts[1]; rf[2] = expf(rp[2]) * ts[2]; rf[3] = expf(rp[3]) * ts[3];
+    if (threadIdx.x < 4) { enc_boxes[row * 4 + threadIdx.x] = from_f32<T>(ts[threadIdx.x]); ref_out[row * 4 + threadIdx.x] = rf[threadIdx.x]; }
+    const float vx = vr[(long)b * L * 2], vy = vr[(long)b * L * 2 + 1];
+    const float pos[4] = {rf[1] * vy, rf[0] * vx, rf[2] * vx, rf[3] * vy};      // order (y, x, w, h)
+    const int half = d / 2;
+    for (int c = threadIdx.x; c < 2 * d; c += blockDim.x) {
+        const int k = c / half, i = c - k * half;
+        const float e = pos[k] * 6.283185307179586f / dim_t[i];
+        sine[row * 2 * d + c] = from_f32<T>((i & 1) ? cosf(e) : sinf(e));
+    }
+    for (int c = threadIdx.x; c < d; c += blockDim.x) xdec[row * d + c] = query_feat[(long)q * d + c];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void box_reparam_kernel(const T* __restrict__ delta, const float* __restrict__ ref, long ref_rows,
+                                                          T* __restrict__ out, long R) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* rf = ref + (r % ref_rows) * 4;
+    const float d0 = to_f32<T>(delta[r * 4]), d1 = to_f32<T>(delta[r * 4 + 1]), d2 = to_f32<T>(delta[r * 4 + 2]), d3 = to_f32<T>(delta[r * 4 + 3]);
+    out[r * 4] = from_f32<T>(d0 * rf[2] + rf[0]);
+    out[r * 4 + 1] = from_f32<T>(d1 * rf[3] + rf[1]);
+    out[r * 4 + 2] = from_f32<T>(expf(d2) * rf[2]);
+    out[r * 4 + 3] = from_f32<T>(expf(d3) * rf[3]);
+}
+
+}  // namespace
+
+#define LWDETR_DISPATCH_T(dtype, CALL)                 \
+    switch (dtype) {                                   \
+        case DT_F32: { typedef float TT; CALL; break; } \
+        case DT_F16: { typedef f16 TT; CALL; break; }   \
+        case DT_BF16: { typedef bf16 TT; CALL; break; } \
+        default: return LWDETR_ERR_UNSUPPORTED;        \
+    }
+
+extern "C" int lwdetr_select_gather(const void* om, const void* enc_cls, long ldc, const float* props, const int64_t* idx,
+                                    void* om_sel, void* logits_out, float* props_sel, int B, int S, int d, int nq, int ncls,
+                                    int dtype, void* hip_stream) {
+    if (!om || !enc_cls || !props || !idx || !om_sel || !logits_out || !props_sel || B <= 0 || nq <= 0) return LWDETR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_ELTWISE, 0.0, 2.0 * B * nq * (d + ncls) * 2, st);
+    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((select_gather_kernel<TT>), dim3(B * nq), dim3(256), 0, st, (const TT*)om,
+                                                (const TT*)enc_cls, ldc, props, idx, (TT*)om_sel, (TT*)logits_out, props_sel, B,
+                                                S, d, nq, ncls));
+    return lwdetr_check_launch();
+}
+
+extern "C" int lwdetr_decoder_inputs(const void* enc_delta, const float* props_sel, const float* refpoint, const float* valid_ratios,
+                                     int L, const void* query_feat, const float* dim_t, void* enc_boxes_out, float* ref_out,
+                                     void* sine_out, void* xdec_out, int B, int nq, int d, int dtype, void* hip_stream) {
+    if (!enc_delta || !props_sel || !refpoint || !valid_ratios || !query_feat || !dim_t || !enc_boxes_out || !ref_out ||
+        !sine_out || !xdec_out || B <= 0 || nq <= 0 || d % 2) return LWDETR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_ELTWISE, 0.0, 3.0 * B * nq * d * 2, st);
+    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((decoder_inputs_kernel<TT>), dim3(B * nq), dim3(256), 0, st, (const TT*)enc_delta,
+                                                props_sel, refpoint, valid_ratios, L, (const TT*)query_feat, dim_t,
+                                                (TT*)enc_boxes_out, ref_out, (TT*)sine_out, (TT*)xdec_out, B, nq, d));
+    return lwdetr_check_launch();
+}
+
+extern "C" int lwdetr_box_reparam(const void* delta, const float* ref, long ref_rows, void* out, long R, int dtype, void* hip_stream) {
+    if (!delta || !ref || !out || R < 0 || ref_rows <= 0) return LWDETR_ERR_BAD_ARG;
+    if (R == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_ELTWISE, 0.0, 0.0, st);
+    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((box_reparam_kernel<TT>), dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
+                                                (const TT*)delta, ref, ref_rows, (TT*)out, R));
+    return lwdetr_check_launch();
+}

@@ -161,7 +161,7 @@ class ForwardPlan:
         pw, C, B, Tp, rows, heads, hd = self.pw, self.C, self.B, self.Tp, self.rows, self.heads, self.hd
         z, ops = self._z, self.ops_backbone
         pre = "backbone.0.encoder"
-        self.images = z(B, 3, self.H, self.W)
+        self.images = None           # allocated only if the caller's tensor cannot be read in place
         self.x = z(rows, C)
         xn, att = z(rows, C), z(rows, C)
         hid = None if K.mlp_fused_supported(C, self.T) else z(rows, 4 * C)
@@ -171,9 +171,11 @@ class ForwardPlan:
         pos = pw.custom(f"pos.{self.Hp}x{self.Wp}", lambda: abs_pos_winmajor(pw.sd[pre + ".pos_embed"].detach().cpu(),
                                                                            self.Hp, self.Wp, self.Twp))
         wpe = pw.w(pre + ".patch_embed.proj.weight", lambda t: t.reshape(t.shape[0], -1))
-        ops.append(GemmOp(self.images, wpe, rows, C, 768, [
+        dummy_img = z(1, 8)
+        ops.append(GemmOp(dummy_img, wpe, rows, C, 768, [
             seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp)],
             a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
+        self.patch_op = ops[-1]
         qscale = K.attention_scale(hd)
         for i in range(self.depth):
             blk = f"{pre}.blocks.{i}"
@@ -406,7 +408,28 @@ class ForwardPlan:
             seg(self.logits, 0, self.ncls, ldo=self.ldc, bias=pw.f("class_embed.bias"))]))
         self.query_feat = pw.w("query_feat.weight", lambda w_: w_[:nq], "g0")
         self.refpoint = pw.f("refpoint_embed.weight", lambda w_: w_[:nq], "g0")
-        self._prop_cache = None
+        # ---- fused glue launches (gather of the selected rows, decoder inputs, final boxes)
+        code = K._nat.dtype_code(self.T)
+        f32 = lambda *s_: torch.zeros(*s_, dtype=torch.float32, device=dev)
+        self._pad_state = None
+        props0, valid0 = self._proposals(None)
+        self._props_static, self._valid_static = props0.contiguous(), valid0.reshape(-1).to(torch.uint8)
+        self.props = self._props_static.clone()
+        self.topk_idx = torch.zeros(B, nq, dtype=torch.int64, device=dev)
+        self.enc_logits_sel, self.enc_boxes = z(B, nq, self.ncls), z(B, nq, 4)
+        self.props_sel = f32(B, nq, 4)
+        self.coord = z(nl, B, nq, 4)
+        dim_t = torch.arange(d // 2, dtype=torch.float32, device=dev)
+        self.dim_t = (10000 ** (2 * (dim_t // 2) / (d // 2))).contiguous()          # transformer.py:46-47
+        ptr = lambda t_: t_.data_ptr()
+        self.op_gather = K.RawOp("lwdetr_select_gather", (
+            ptr(self.om), ptr(self.enc_cls), self.ldc, ptr(self.props), ptr(self.topk_idx), ptr(self.om_sel),
+            ptr(self.enc_logits_sel), ptr(self.props_sel), B, S, d, nq, self.ncls, code), keep=())
+        self.op_dec_inputs = K.RawOp("lwdetr_decoder_inputs", (
+            ptr(self.enc_delta), ptr(self.props_sel), ptr(self.refpoint), ptr(self.vr), L, ptr(self.query_feat),
+            ptr(self.dim_t), ptr(self.enc_boxes), ptr(self.ref), ptr(self.sine), ptr(self.xdec), B, nq, d, code), keep=())
+        self.op_boxes = K.RawOp("lwdetr_box_reparam", (
+            ptr(self.delta), ptr(self.ref), B * nq, ptr(self.coord), nl * B * nq, code), keep=())
 
     # ------------------------------------------------------------------------------- per-call host-side glue
     def _masks(self, mask):
@@ -443,54 +466,61 @@ class ForwardPlan:
         return props, valid
 
     @torch.no_grad()
+    def _set_padding_state(self, mask):
+        """Per-call masks -> row masks, valid ratios and anchor proposals; the no-padding state is set once and reused."""
+        has_pad = mask is not None and bool(mask.any())
+        if not has_pad:
+            if self._pad_state != "nopad":
+                self.props.copy_(self._props_static)
+                self.rowvalid.copy_(self._valid_static)
+                self.notpad.fill_(1)
+                self.vr.fill_(1.0)
+                self._pad_state = "nopad"
+            return
+        mask_flat, vr = self._masks(mask)
+        props, valid = self._proposals(mask_flat)
+        self.props.copy_(props)
+        self.rowvalid.copy_(valid.reshape(-1).to(torch.uint8))
+        self.notpad.copy_((~mask_flat).reshape(-1).to(torch.uint8))
+        self.vr.copy_(vr)
+        self._pad_state = "pad"
+
+    @torch.no_grad()
     def run(self, images, mask=None, forced_topk=None, collect=None):
         """images (B,3,H,W) on the plan's device; mask (B,H,W) bool or None (= no padding)."""
         B, S, d, nq, T = self.B, self.S, self.d, self.nq, self.T
         stream = K._nat.stream_ptr(self.dev)
-        self.images.copy_(images)
-        has_pad = mask is not None and bool(mask.any())
-        if has_pad:
-            mask_flat, vr = self._masks(mask)
-            props, valid = self._proposals(mask_flat)
-            self.notpad.copy_((~mask_flat).reshape(-1).to(torch.uint8))
-            self.vr.copy_(vr)
+        if images.dtype == T and images.is_contiguous() and images.device == self.x.device:
+            self._img_ref = images                                   # the patch GEMM reads the caller's tensor in place
         else:
-            if self._prop_cache is None:
-                self._prop_cache = self._proposals(None)
-            props, valid = self._prop_cache
-            self.notpad.fill_(1)
-            self.vr.fill_(1.0)
-        self.rowvalid.copy_(valid.reshape(-1).to(torch.uint8))
+            if self.images is None:
+                self.images = self._z(B, 3, self.H, self.W)
+            self.images.copy_(images)
+            self._img_ref = self.images
+        self.patch_op.desc.A = self._img_ref.data_ptr()
+        self._set_padding_state(mask)
         for op in self.ops_backbone:
             op(stream)
         for op in self.ops_enc:
             op(stream)
         # ---- two-stage selection (group 0 only at inference, transformer.py:229-264)
-        enc_cls = self.enc_cls.view(B, S, self.ldc)[:, :, :self.ncls]
-        cls_max = enc_cls.float().max(-1)[0]
+        cls_max = self.enc_cls.view(B, S, self.ldc)[:, :, :self.ncls].max(-1)[0].float()
         topk = torch.topk(cls_max, nq, dim=1)[1] if forced_topk is None else forced_topk.to(self.dev)
-        gi = topk.unsqueeze(-1)
-        self.om_sel.copy_(torch.gather(self.om.view(B, S, d), 1, gi.expand(-1, -1, d)).reshape(B * nq, d))
+        self.topk_idx.copy_(topk)
+        self.op_gather(stream)
         for op in self.ops_sel:
             op(stream)
-        props_sel = torch.gather(props, 1, gi.expand(-1, -1, 4))
-        ref_ts = reparam(self.enc_delta.view(B, nq, 4).float(), props_sel)
-        enc_logits = torch.gather(enc_cls, 1, gi.expand(-1, -1, self.ncls))
-        # ---- decoder inputs (transformer.py:266-276, :344-364)
-        self.xdec.copy_(self.query_feat.unsqueeze(0).expand(B, -1, -1).reshape(B * nq, d))
-        ref = reparam(self.refpoint.unsqueeze(0).expand(B, -1, -1), ref_ts)
-        self.ref.copy_(ref)
-        ref0 = ref * torch.cat([self.vr[:, 0], self.vr[:, 0]], -1)[:, None]
-        self.sine.copy_(sine_embed(ref0, d // 2).reshape(B * nq, 2 * d))
+        self.op_dec_inputs(stream)
         for op in self.ops_dec:
             op(stream)
+        self.op_boxes(stream)
         nl = self.cfg.dec_layers
-        coord = reparam(self.delta.view(nl, B, nq, 4).float(), ref[None]).to(T)
         cls = self.logits.view(nl, B, nq, self.ldc)[..., :self.ncls].clone()
+        coord = self.coord.clone()
         out = {"pred_logits": cls[-1], "pred_boxes": coord[-1]}
         if self.cfg.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(cls[:-1], coord[:-1])]
-        out["enc_outputs"] = {"pred_logits": enc_logits.clone(), "pred_boxes": ref_ts.to(T)}
+        out["enc_outputs"] = {"pred_logits": self.enc_logits_sel.clone(), "pred_boxes": self.enc_boxes.clone()}
         if collect is not None:
             collect.update({"topk_idx": topk, "enc.class_max": cls_max, "memory": self.memory.view(B, S, d).clone(),
                             "taps_cat": self.taps_cat.clone(), "x": self.x.clone(), "hs": self.hs.clone(),

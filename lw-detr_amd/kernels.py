@@ -155,6 +155,19 @@ class MlpFusedOp:
             _nat.check(rc, "mlp_fused")
 
 
+class RawOp:
+    """Generic pre-bound launch: ``fn(*args, stream)`` of the C ABI (keeps the tensors behind the pointers alive)."""
+
+    def __init__(self, name, args, keep):
+        self.name, self.args, self._keep = name, tuple(args), keep
+        self._fn = getattr(_nat.lib(), name)
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, self.name)
+
+
 class MsdaFusedOp:
     def __init__(self, value, shapes, lsi, oa, ld_oa, logit_col, ref, vr, out, *, B, S, M, D, L, Q, P):
         assert ref.dtype == torch.float32 and vr.dtype == torch.float32

@@ -84,10 +84,15 @@ class LWDETR(nn.Module):
     def forward(self, samples, targets=None, _forced_topk=None, _collect=None):
         """samples: NestedTensor | list[Tensor(3,h,w)] | Tensor(B,3,H,W). Returns the reference's output dict:
         pred_logits (B,nq,C), pred_boxes (B,nq,4) cxcywh, aux_outputs (dec_layers-1 dicts), enc_outputs."""
-        if isinstance(samples, (list, torch.Tensor)):
-            samples = nested_tensor_from_tensor_list(samples)
-        x, mask = samples.tensors, samples.mask
-        assert mask is not None
+        if isinstance(samples, torch.Tensor):
+            x, mask = samples, None                     # a dense batch has no padding: no mask work, no host sync
+        else:
+            if isinstance(samples, list):
+                same = all(t.shape == samples[0].shape for t in samples)
+                samples = nested_tensor_from_tensor_list(samples)
+                if same:
+                    samples.mask = None
+            x, mask = samples.tensors, samples.mask
         b, _, h, w = x.shape
         plan = self._plan(b, h, w)
         with torch.cuda.device(plan.dev):
