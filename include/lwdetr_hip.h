@@ -128,10 +128,14 @@ int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* b
  *   w2_chunked (4C/32, C, 32) = fc2.weight.view(C, 4C/32, 32)[:, :, perm].permute(1, 0, 2): each 32-wide hidden chunk
  *   contiguous, inside a chunk perm = [4g+e+16*hi for g in 0..3 for hi in 0..1 for e in 0..3] (the kernel's MFMA k-slots).
  * x is updated in place; out2 (optional, row stride ld2) receives a copy (ViT feature taps); stats_out (optional, (M,2)
- * f32) receives mean and 1/sqrt(var+eps_next) of the updated rows for the next block's LayerNorm. C in {192, 384}. */
+ * f32) receives mean and 1/sqrt(var+eps_next) of the updated rows for the next block's LayerNorm. C in {192, 384}.
+ * Optional fused attention output projection (vit.py:138, :206-216): when att != NULL the kernel first computes
+ * x <- x + gamma1 * (att @ wp^T + bp) (att (M,C) row stride ldatt, wp (C,C) = attn.proj.weight, bp / gamma1 f32 (C));
+ * w1_folded must then have its columns permuted inside every 32-chunk with the same `perm` as w2_chunked. */
 int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_folded, const void* w2_chunked,
                      const float* b2, const float* gamma2, void* out2, long ld2, float* stats_out, long M, int C,
-                     float eps, float eps_next, int dtype, void* hip_stream);
+                     float eps, float eps_next, const void* att, long ldatt, const void* wp, const float* bp,
+                     const float* gamma1, int dtype, void* hip_stream);
 
 /* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
  * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */

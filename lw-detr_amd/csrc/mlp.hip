@@ -34,9 +34,11 @@ struct MlpParams {
     void* out2; long ld2;              // optional second destination
     float* stats_out;                  // optional (M, 2): mean, rstd of the updated rows (eps_next)
     long M; float eps, eps_next;
+    // optional fused attention output projection: x <- x + gamma1 * (att Wp^T + bp) before the MLP
+    const void* att; long ldatt; const void* wp; const float* bp; const float* gamma1;
 };
 
-template <typename T, int C, int TT>
+template <typename T, int C, int TT, bool PROJ>
 __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
@@ -101,24 +103,95 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
                                                  (__attribute__((address_space(3))) void*)(w2s + i * 64 * EPC), 16, 0, 0);
         }
     };
-    stage_w(0, 0);
-    // fc1 bias -> LDS once (ordinary global loads inside the loop would force an early drain of the DMA queue)
+    // fc1 bias (and the projection's bias / LayerScale) -> LDS once: ordinary global loads inside the loops would force
+    // an early drain of the DMA queue
     float* b1s = (float*)(smem + 2 * TILE_STRIDE);
     for (int i = tid; i < HID; i += 256) b1s[i] = p.b1[i];
+    float* bps = b1s + HID;
+    if (PROJ) for (int i = tid; i < C; i += 256) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; }
 
-    // ---- prologue: token rows -> normalised B-operand fragments
+    // ---- prologue: token rows -> B-operand fragments xf (lane: token l15, 8 channels per k-chunk)
     V8 xf[TT][KC];
+    if (!PROJ) {
+        stage_w(0, 0);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            long m = m_wave + t * 16 + l15; m = m < p.M ? m : p.M - 1;
+            const T* xr = X + m * p.ldx + g * 8;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) xf[t][kc] = *(const V8*)(xr + kc * 32);
+        }
+    } else {
+        // Fused attention output projection (reference vit.py:138, :206-216): x1 = x + gamma1 * (att Wp^T + bp), computed
+        // as D[channel][token] so that the accumulators of two adjacent 16-channel tiles ARE the next MFMA's k-run
+        // (slots 0-3 <- channels 32pc+4g.., slots 4-7 <- 32pc+16+4g..; fc1's columns are permuted to match on the host).
+        // Wp streams through the W1 tile buffers in pieces of 32 output channels.
+        const T* __restrict__ ATT = (const T*)p.att;
+        const T* __restrict__ WP = (const T*)p.wp;
+        auto stage_rows32 = [&](const T* src, int buf) {
+            T* w1s = smem + buf * TILE_STRIDE;
+#pragma unroll
+            for (int k = 0; k < W1_MY; ++k) {
+                const int i = wave + 4 * k;
+                if (i < W1_INSTR)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off1[k]),
+                                                     (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
+            }
+        };
+        stage_rows32(WP, 0);
+        V8 af[TT][KC];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            long m = m_wave + t * 16 + l15; m = m < p.M ? m : p.M - 1;
+            const T* ar = ATT + m * p.ldatt + g * 8;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) af[t][kc] = *(const V8*)(ar + kc * 32);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pc = 0; pc < KC; ++pc) {
+            const int buf = pc & 1;
+            if (pc + 1 < KC) stage_rows32(WP + (long)(pc + 1) * 32 * C, buf ^ 1);
+            else stage_w(0, buf ^ 1);                    // KC is even: the last piece sits in buffer 1, chunk 0 goes to 0
+            const T* wps = smem + buf * TILE_STRIDE;
+            f32x4 accp[2][TT];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) accp[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const V8 a = *(const V8*)(wps + (h * 16 + l15) * W1_LD + kc * 32 + g * 8);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) accp[h][t] = Mma<T>::k32(a, af[t][kc], accp[h][t]);
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c0 = pc * 32 + h * 16 + g * 4;
+                const f32x4 bb = *(const f32x4*)(bps + c0), gg = *(const f32x4*)(bps + C + c0);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const long m = m_wave + t * 16 + l15;
+                    const long mr = m < p.M ? m : p.M - 1;
+                    const V4 x1 = cvt4<T>(up4<T>(*(const V4*)(X + mr * p.ldx + c0)) + gg * (accp[h][t] + bb));
+                    if (m < p.M) *(V4*)(X + m * p.ldx + c0) = x1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xf[t][pc][h * 4 + e] = x1[e];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- LayerNorm in registers (two-pass f32 statistics; the affine part is folded into W1 / b1 on the host)
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        long m = m_wave + t * 16 + l15; m = m < p.M ? m : p.M - 1;
-        const T* xr = X + m * p.ldx + g * 8;
         float s = 0.f;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            xf[t][kc] = *(const V8*)(xr + kc * 32);
+        for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += to_f32<T>(xf[t][kc][e]);
-        }
         s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
         const float mean = s * (1.f / C);
         float v = 0.f;
@@ -140,7 +213,7 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc2[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    __syncthreads();
+    if (!PROJ) __syncthreads();
     for (int hc = 0; hc < NCH; ++hc) {
         const int buf = hc & 1;
         if (hc + 1 < NCH) stage_w(hc + 1, buf ^ 1);
@@ -222,22 +295,27 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
     }
 }
 
-template <typename T, int C, int TT>
-int launch_mlp(const MlpParams& p, hipStream_t st) {
+template <typename T, int C, int TT, bool PROJ>
+int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int PIECE = 64 * EPC;
     constexpr int W1P = (32 * (C + 2 * EPC) + PIECE - 1) / PIECE * PIECE, W2P = (C * (32 + 2 * EPC) + PIECE - 1) / PIECE * PIECE;
-    constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 4 * C * sizeof(float);
+    constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 6 * C * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
         attr_done = true;
     }
     const long blocks = (p.M + 64 * TT - 1) / (64 * TT);
-    ProfScope ps(KID_MLP, 16.0 * p.M * C * C, (double)p.M * C * sizeof(T) * 2 + 8.0 * C * C * sizeof(T), st);
-    hipLaunchKernelGGL((mlp_kernel<T, C, TT>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    ProfScope ps(KID_MLP, (PROJ ? 18.0 : 16.0) * p.M * C * C, (double)p.M * C * sizeof(T) * (PROJ ? 3 : 2) + 8.0 * C * C * sizeof(T), st);
+    hipLaunchKernelGGL((mlp_kernel<T, C, TT, PROJ>), dim3((unsigned)blocks), dim3(256), lds, st, p);
     return lwdetr_check_launch();
+}
+
+template <typename T, int C, int TT>
+int launch_mlp(const MlpParams& p, hipStream_t st) {
+    return p.att ? launch_mlp_p<T, C, TT, true>(p, st) : launch_mlp_p<T, C, TT, false>(p, st);
 }
 
 template <typename T, int TT16, int TT32>
@@ -253,11 +331,14 @@ int dispatch_c(const MlpParams& p, int C, hipStream_t st) {
 
 extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_folded, const void* w2_chunked,
                                 const float* b2, const float* gamma2, void* out2, long ld2, float* stats_out, long M,
-                                int C, float eps, float eps_next, int dtype, void* hip_stream) {
+                                int C, float eps, float eps_next, const void* att, long ldatt, const void* wp,
+                                const float* bp, const float* gamma1, int dtype, void* hip_stream) {
     if (!x || !w1_folded || !b1_folded || !w2_chunked || !b2 || !gamma2 || M < 0) return LWDETR_ERR_BAD_ARG;
     if (M == 0) return LWDETR_OK;
     if (ldx % 8 != 0 || (out2 && ld2 % 8 != 0)) return LWDETR_ERR_BAD_ARG;
+    if (att && (!wp || !bp || !gamma1 || ldatt % 8 != 0)) return LWDETR_ERR_BAD_ARG;
     MlpParams p;
+    p.att = att; p.ldatt = ldatt; p.wp = wp; p.bp = bp; p.gamma1 = gamma1;
     p.x = x; p.ldx = ldx; p.w1 = w1_folded; p.b1 = b1_folded; p.w2p = w2_chunked; p.b2 = b2; p.gamma2 = gamma2;
     p.out2 = out2; p.ld2 = ld2; p.stats_out = stats_out; p.M = M; p.eps = eps; p.eps_next = eps_next;
     hipStream_t st = (hipStream_t)hip_stream;

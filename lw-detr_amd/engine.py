@@ -192,19 +192,24 @@ class ForwardPlan:
             else:
                 ops.append(AttnOp(q, k, vt, att, B=B, heads=heads, hd=hd, Tp=Tp, ldo=C, seqs_per_img=1,
                                   seq_tok_stride=Tp, keys_per_seq=Tp, sub_stride=self.Twp, sub_len=self.Tw, kind=1))
-            ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
-                seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
-                    res=self.x, ldres=C)]))
+            fused = K.mlp_fused_supported(C, self.T)
+            if not fused:
+                ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
+                    seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
+                        res=self.x, ldres=C)]))
             tap_out = None
             if i in self.taps:
                 j = self.taps.index(i)
                 tap_out = self.taps_cat[:, j * C:]
-            if K.mlp_fused_supported(C, self.T):
+            if fused:
+                # one launch: x += gamma1 * proj(att); x += gamma2 * fc2(GELU(fc1(LN(x))))  (vit.py:206-218)
                 w1f, b1f, w2c = pw.custom_multi(blk + ".mlp.packed", lambda blk=blk: K.pack_mlp_weights(
                     pw.sd[blk + ".mlp.fc1.weight"], pw.sd[blk + ".mlp.fc1.bias"], pw.sd[blk + ".mlp.fc2.weight"],
-                    pw.sd[blk + ".norm2.weight"], pw.sd[blk + ".norm2.bias"], self.T))
+                    pw.sd[blk + ".norm2.weight"], pw.sd[blk + ".norm2.bias"], self.T, proj=True))
                 ops.append(K.MlpFusedOp(self.x, w1f, b1f, w2c, pw.f(blk + ".mlp.fc2.bias"), pw.f(blk + ".gamma_2"), rows,
-                                        C, 1e-6, out2=tap_out, ld2=ntap * C))
+                                        C, 1e-6, out2=tap_out, ld2=ntap * C, att=att, ldatt=C,
+                                        wp=pw.w(blk + ".attn.proj.weight"), bp=pw.f(blk + ".attn.proj.bias"),
+                                        gamma1=pw.f(blk + ".gamma_1")))
             else:
                 ops.append(LayerNormOp(self.x, pw.f(blk + ".norm2.weight"), pw.f(blk + ".norm2.bias"), xn, rows, C, 1e-6))
                 ops.append(GemmOp(xn, pw.w(blk + ".mlp.fc1.weight"), rows, 4 * C, C, [

@@ -123,16 +123,22 @@ def mlp_fused_supported(C_, dtype) -> bool:
     return C_ == 192 or (C_ == 384 and dtype in (torch.float16, torch.bfloat16))
 
 
-def pack_mlp_weights(w1, b1, w2, ln_w, ln_b, dtype):
+_KSLOT_PERM = [4 * g_ + e + 16 * hi for g_ in range(4) for hi in range(2) for e in range(4)]
+
+
+def pack_mlp_weights(w1, b1, w2, ln_w, ln_b, dtype, proj=False):
     """Host-side packing for lwdetr_mlp_fused (f32 master tensors in, device tensors of ``dtype`` / f32 out):
     LayerNorm's affine is folded into fc1, fc2 is re-laid out chunk-major (32 hidden units per contiguous tile)."""
     w1, b1, w2, ln_w, ln_b = (t.float() for t in (w1, b1, w2, ln_w, ln_b))
     c = w1.shape[1]
-    w1f = (w1 * ln_w[None, :]).to(dtype).contiguous()
     b1f = (b1 + w1 @ ln_b).contiguous()
+    w1f = w1 * ln_w[None, :]
+    if proj:   # the fused projection hands x over in accumulator order: permute fc1's columns inside every 32-chunk
+        w1f = w1f.view(4 * c, c // 32, 32)[:, :, torch.tensor(_KSLOT_PERM)].reshape(4 * c, c)
+    w1f = w1f.to(dtype).contiguous()
     # chunk-major, and inside a chunk the MFMA k-slot order of the fused kernel: lane group g holds hidden
     # (4g..4g+3, 16+4g..16+4g+3) as one contiguous run of 8
-    perm = torch.tensor([4 * g_ + e + 16 * hi for g_ in range(4) for hi in range(2) for e in range(4)])
+    perm = torch.tensor(_KSLOT_PERM)
     w2c = w2.view(c, (4 * c) // 32, 32)[:, :, perm].permute(1, 0, 2).to(dtype).contiguous()
     return w1f, b1f, w2c
 
@@ -141,12 +147,15 @@ class MlpFusedOp:
     """x <- x + gamma2 * fc2(GELU(fc1(LN(x)))) in one launch (weights packed by ``pack_mlp_weights``)."""
 
     def __init__(self, x, w1f, b1f, w2c, b2, gamma2, M, C_, eps, *, ldx=None, out2=None, ld2=0, stats_out=None,
-                 eps_next=1e-6):
+                 eps_next=1e-6, att=None, ldatt=None, wp=None, bp=None, gamma1=None):
         assert b1f.dtype == torch.float32 and b2.dtype == torch.float32 and gamma2.dtype == torch.float32
         assert w1f.dtype == x.dtype and w2c.dtype == x.dtype and w1f.is_contiguous() and w2c.is_contiguous()
         self.args = (_ptr(x), ldx if ldx is not None else C_, _ptr(w1f), _ptr(b1f), _ptr(w2c), _ptr(b2), _ptr(gamma2),
-                     _ptr(out2), ld2, _ptr(stats_out), M, C_, float(eps), float(eps_next), _nat.dtype_code(x.dtype))
-        self._keep = (x, w1f, b1f, w2c, b2, gamma2, out2, stats_out)
+                     _ptr(out2), ld2, _ptr(stats_out), M, C_, float(eps), float(eps_next), _ptr(att),
+                     ldatt if ldatt is not None else C_, _ptr(wp), _ptr(bp), _ptr(gamma1), _nat.dtype_code(x.dtype))
+        if att is not None:
+            assert wp.dtype == x.dtype and wp.is_contiguous() and bp.dtype == torch.float32 and gamma1.dtype == torch.float32
+        self._keep = (x, w1f, b1f, w2c, b2, gamma2, out2, stats_out, att, wp, bp, gamma1)
         self._fn = _nat.lib().lwdetr_mlp_fused
 
     def __call__(self, stream=None):

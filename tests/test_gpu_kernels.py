@@ -243,6 +243,16 @@ def test_mlp_fused(dtype, c, m):
     mean, var = xx.float().mean(1), xx.float().var(1, unbiased=False)
     assert (stats[:, 0] - mean).abs().max().item() < 1e-4
     assert ((stats[:, 1] - (var + 1e-6).rsqrt()).abs() / (var + 1e-6).rsqrt()).max().item() < 1e-4
+    # with the attention output projection fused in front: x1 = x + g1 * (att Wp^T + bp), then the MLP on x1
+    att = _rand(m, c, dtype=dtype, seed=9)
+    wp, bp, g1 = _rand(c, c, scale=c ** -0.5, seed=10), _rand(c, seed=11) * 0.1, _rand(c, seed=12) * 0.3
+    x1 = xf + g1 * (att.float() @ wp.t() + bp)
+    x1r = x1.to(dtype).float()                      # the kernel rounds x1 to the storage type before the MLP
+    ref2 = x1r + g2 * (F.gelu(F.layer_norm(x1r, (c,), lw, lb, 1e-6) @ w1.t() + b1) @ w2.t() + b2)
+    w1p, b1p, w2p = K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype, proj=True)
+    xx = x.clone()
+    K.MlpFusedOp(xx, w1p, b1p, w2p, b2, g2, m, c, 1e-6, att=att, wp=wp.to(dtype).contiguous(), bp=bp, gamma1=g1)()
+    assert _relerr(xx, ref2) < tol, _relerr(xx, ref2)
 
 
 def test_gemm_rejects_bad_arguments():

@@ -87,6 +87,11 @@ def bench_mlp(batch=32, C=192, dtype=torch.float16):
     lw, lb, g2 = torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.rand(C, device=dev) * 0.3
     w1f, b1f, w2c = (t.to(dev) for t in K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype))
     op = K.MlpFusedOp(x, w1f, b1f, w2c, b2, g2, M, C, 1e-6)
+    us0 = timeit(op)
+    att = torch.randn(M, C, device=dev).to(dtype); wp = (torch.randn(C, C, device=dev) * C ** -0.5).to(dtype)
+    w1p, b1p, w2p = (t.to(dev) for t in K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype, proj=True))
+    op = K.MlpFusedOp(x, w1p, b1p, w2p, b2, g2, M, C, 1e-6, att=att, wp=wp, bp=b2, gamma1=g2)
+    print(f"mlp_fused (no proj) C={C}: {us0:8.1f} us")
     us = timeit(op)
     print(f"mlp_fused C={C}: {us:8.1f} us  {16.0 * M * C * C / us / 1e6:7.1f} TFLOP/s")
 
