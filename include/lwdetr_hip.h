@@ -131,11 +131,16 @@ int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* b
  * f32) receives mean and 1/sqrt(var+eps_next) of the updated rows for the next block's LayerNorm. C in {192, 384}.
  * Optional fused attention output projection (vit.py:138, :206-216): when att != NULL the kernel first computes
  * x <- x + gamma1 * (att @ wp^T + bp) (att (M,C) row stride ldatt, wp (C,C) = attn.proj.weight, bp / gamma1 f32 (C));
- * w1_folded must then have its columns permuted inside every 32-chunk with the same `perm` as w2_chunked. */
+ * w1_folded must then have its columns permuted inside every 32-chunk with the same `perm` as w2_chunked.
+ * Optional chained LayerNorm + QKV of the NEXT block (vit.py:199, :123-130) on the updated rows (needs att != NULL):
+ * wqkv_next (3C, C) = next qkv.weight * next norm1.weight[None,:] with the same per-32-chunk column permutation,
+ * bqkv_next (3C) f32 = [q_bias, 0, v_bias] + qkv.weight @ norm1.bias; writes Q (pre-scaled by qscale), K as
+ * (B, heads, Tp, hd) and V^T as (B, heads, hd, Tp) exactly like lwdetr_gemm's HEADS / HEADS_T epilogues (LN eps = eps_next). */
 int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_folded, const void* w2_chunked,
                      const float* b2, const float* gamma2, void* out2, long ld2, float* stats_out, long M, int C,
                      float eps, float eps_next, const void* att, long ldatt, const void* wp, const float* bp,
-                     const float* gamma1, int dtype, void* hip_stream);
+                     const float* gamma1, const void* wqkv_next, const float* bqkv_next, void* q_out, void* k_out,
+                     void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream);
 
 /* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
  * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */

@@ -71,7 +71,8 @@ def lib():
         l.lwdetr_gemm.argtypes = [C.POINTER(GemmDesc), i, vp]
         l.lwdetr_attention.argtypes = [C.POINTER(AttnDesc), i, vp]
         l.lwdetr_layernorm.argtypes = [vp, lg, vp, vp, vp, lg, lg, i, f, lg, lg, lg, i, vp]
-        l.lwdetr_mlp_fused.argtypes = [vp, lg, vp, vp, vp, vp, vp, vp, lg, vp, lg, i, f, f, vp, lg, vp, vp, vp, i, vp]
+        l.lwdetr_mlp_fused.argtypes = [vp, lg, vp, vp, vp, vp, vp, vp, lg, vp, lg, i, f, f, vp, lg, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, f, i, i, i, i, vp]
         l.lwdetr_select_gather.argtypes = [vp, vp, lg, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         l.lwdetr_decoder_inputs.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
         l.lwdetr_box_reparam.argtypes = [vp, vp, lg, vp, lg, i, vp]

@@ -36,9 +36,11 @@ struct MlpParams {
     long M; float eps, eps_next;
     // optional fused attention output projection: x <- x + gamma1 * (att Wp^T + bp) before the MLP
     const void* att; long ldatt; const void* wp; const float* bp; const float* gamma1;
+    // optional chained LayerNorm + QKV projection of the NEXT block on the updated rows (vit.py:199, :123-130)
+    const void* wqkv; const float* bqkv; void* q; void* k; void* vt; float qscale; int heads, hd, Tp;
 };
 
-template <typename T, int C, int TT, bool PROJ>
+template <typename T, int C, int TT, bool PROJ, bool QKV>
 __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
@@ -103,12 +105,25 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
                                                  (__attribute__((address_space(3))) void*)(w2s + i * 64 * EPC), 16, 0, 0);
         }
     };
+    // a (32 rows x C) weight piece into the W1 slot of buffer `buf` (projection / QKV weights stream through it)
+    auto stage_rows32 = [&](const T* src, int buf) {
+        T* w1s = smem + buf * TILE_STRIDE;
+#pragma unroll
+        for (int k = 0; k < W1_MY; ++k) {
+            const int i = wave + 4 * k;
+            if (i < W1_INSTR)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off1[k]),
+                                                 (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
+        }
+    };
     // fc1 bias (and the projection's bias / LayerScale) -> LDS once: ordinary global loads inside the loops would force
     // an early drain of the DMA queue
     float* b1s = (float*)(smem + 2 * TILE_STRIDE);
     for (int i = tid; i < HID; i += 256) b1s[i] = p.b1[i];
     float* bps = b1s + HID;
     if (PROJ) for (int i = tid; i < C; i += 256) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; }
+    float* bqs = bps + 2 * C;
+    if (QKV) for (int i = tid; i < 3 * C; i += 256) bqs[i] = p.bqkv[i];
 
     // ---- prologue: token rows -> B-operand fragments xf (lane: token l15, 8 channels per k-chunk)
     V8 xf[TT][KC];
@@ -128,16 +143,6 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
         // Wp streams through the W1 tile buffers in pieces of 32 output channels.
         const T* __restrict__ ATT = (const T*)p.att;
         const T* __restrict__ WP = (const T*)p.wp;
-        auto stage_rows32 = [&](const T* src, int buf) {
-            T* w1s = smem + buf * TILE_STRIDE;
-#pragma unroll
-            for (int k = 0; k < W1_MY; ++k) {
-                const int i = wave + 4 * k;
-                if (i < W1_INSTR)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off1[k]),
-                                                     (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
-            }
-        };
         stage_rows32(WP, 0);
         V8 af[TT][KC];
 #pragma unroll
@@ -256,7 +261,9 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
     }
 
     // ---- epilogue: lane holds channels n*16 + 4g .. +3 of token l15
+    if (QKV) stage_rows32((const T*)p.wqkv, 0);          // first QKV weight piece streams in under the epilogue
     T* __restrict__ O2 = (T*)p.out2;
+    V8 xq[QKV ? TT : 1][QKV ? KC : 1];
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         const long m = m_wave + t * 16 + l15;
@@ -270,7 +277,15 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
             // round to the storage type now: the statistics below describe exactly what the next LayerNorm reads
             acc2[n][t] = up4<T>(cvt4<T>(xr + g2 * (acc2[n][t] + b2)));
         }
-        if (p.stats_out) {
+        if (ok) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const V4 o = cvt4<T>(acc2[n][t]);
+                *(V4*)(X + m * p.ldx + n * 16 + g * 4) = o;
+                if (O2) *(V4*)(O2 + m * p.ld2 + n * 16 + g * 4) = o;
+            }
+        }
+        if (p.stats_out || QKV) {
             float s = 0.f;
 #pragma unroll
             for (int n = 0; n < NT; ++n) s += acc2[n][t][0] + acc2[n][t][1] + acc2[n][t][2] + acc2[n][t][3];
@@ -282,40 +297,124 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float dl = acc2[n][t][e] - mean; v += dl * dl; }
             v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            if (ok && g == 0) { p.stats_out[2 * m] = mean; p.stats_out[2 * m + 1] = 1.f / sqrtf(v * (1.f / C) + p.eps_next); }
-        }
-        if (ok) {
+            const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps_next);
+            if (p.stats_out && ok && g == 0) { p.stats_out[2 * m] = mean; p.stats_out[2 * m + 1] = rstd; }
+            if (QKV) {
+                // normalised rows as B-operand fragments, in accumulator (k-slot) order: the QKV weight's columns carry
+                // the same permutation inside every 32-chunk
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const V4 o = cvt4<T>(acc2[n][t]);
-                *(V4*)(X + m * p.ldx + n * 16 + g * 4) = o;
-                if (O2) *(V4*)(O2 + m * p.ld2 + n * 16 + g * 4) = o;
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xq[t][kc][e] = from_f32<T>((acc2[2 * kc][t][e] - mean) * rstd);
+                        xq[t][kc][4 + e] = from_f32<T>((acc2[2 * kc + 1][t][e] - mean) * rstd);
+                    }
             }
+        }
+    }
+    if (QKV) {
+        // ---- chained LayerNorm + QKV of the next block: 3C/32 pieces of 32 output features through the W1 buffers.
+        // Q, K: D[feature][token] (lane: 4 consecutive features of a head, token l15) -> (B, heads, Tp, hd);
+        // V   : operands swapped, D[token][feature] (lane: 4 consecutive tokens, feature l15) -> V^T (B, heads, hd, Tp).
+        const T* __restrict__ WQ = (const T*)p.wqkv;
+        T* __restrict__ Qo = (T*)p.q; T* __restrict__ Ko = (T*)p.k; T* __restrict__ Vo = (T*)p.vt;
+        constexpr int NP = 3 * C / 32, PSEG = C / 32;
+        __syncthreads();
+#pragma unroll 1
+        for (int pc = 0; pc < NP; ++pc) {
+            const int buf = pc & 1;
+            if (pc + 1 < NP) stage_rows32(WQ + (long)(pc + 1) * 32 * C, buf ^ 1);
+            const T* ws = smem + buf * TILE_STRIDE;
+            const int sg = pc / PSEG;                      // 0 q, 1 k, 2 v
+            f32x4 acc[2][TT];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (sg < 2) {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const V8 a = *(const V8*)(ws + (h * 16 + l15) * W1_LD + kc * 32 + g * 8);
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) acc[h][t] = Mma<T>::k32(a, xq[t][kc], acc[h][t]);
+                    }
+            } else {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const V8 a = *(const V8*)(ws + (h * 16 + l15) * W1_LD + kc * 32 + g * 8);
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) acc[h][t] = Mma<T>::k32(xq[t][kc], a, acc[h][t]);
+                    }
+            }
+            if (sg < 2) {
+                T* __restrict__ dst = sg == 0 ? Qo : Ko;
+                const float sc = sg == 0 ? p.qscale : 1.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nl = (pc - sg * PSEG) * 32 + h * 16 + g * 4;          // feature inside the segment
+                    const f32x4 bb = *(const f32x4*)(bqs + sg * C + nl);
+                    const int hh = nl / p.hd, dd = nl - hh * p.hd;
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const long m = m_wave + t * 16 + l15;
+                        if (m < p.M) {
+                            const long b = m / p.Tp, tk = m - b * p.Tp;
+                            *(V4*)(dst + ((b * p.heads + hh) * p.Tp + tk) * p.hd + dd) = cvt4<T>((acc[h][t] + bb) * sc);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nl = (pc - 2 * PSEG) * 32 + h * 16 + l15;
+                    const float bb = bqs[2 * C + nl];
+                    const int hh = nl / p.hd, dd = nl - hh * p.hd;
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const long m = m_wave + t * 16 + g * 4;
+                        if (m < p.M) {
+                            const long b = m / p.Tp, tk = m - b * p.Tp;
+                            T* dp = Vo + ((b * p.heads + hh) * p.hd + dd) * p.Tp + tk;
+                            const V4 o = cvt4<T>(acc[h][t] + bb);
+                            if (m + 3 < p.M) *(V4*)dp = o;
+                            else for (int e = 0; e < 4; ++e) if (m + e < p.M) dp[e] = o[e];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
 
-template <typename T, int C, int TT, bool PROJ>
+template <typename T, int C, int TT, bool PROJ, bool QKV>
 int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int PIECE = 64 * EPC;
     constexpr int W1P = (32 * (C + 2 * EPC) + PIECE - 1) / PIECE * PIECE, W2P = (C * (32 + 2 * EPC) + PIECE - 1) / PIECE * PIECE;
-    constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 6 * C * sizeof(float);
+    constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 9 * C * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, PROJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
         attr_done = true;
     }
     const long blocks = (p.M + 64 * TT - 1) / (64 * TT);
-    ProfScope ps(KID_MLP, (PROJ ? 18.0 : 16.0) * p.M * C * C, (double)p.M * C * sizeof(T) * (PROJ ? 3 : 2) + 8.0 * C * C * sizeof(T), st);
-    hipLaunchKernelGGL((mlp_kernel<T, C, TT, PROJ>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    ProfScope ps(KID_MLP, (16.0 + (PROJ ? 2.0 : 0.0) + (QKV ? 6.0 : 0.0)) * p.M * C * C, (double)p.M * C * sizeof(T) * (PROJ ? 3 : 2) + 8.0 * C * C * sizeof(T), st);
+    hipLaunchKernelGGL((mlp_kernel<T, C, TT, PROJ, QKV>), dim3((unsigned)blocks), dim3(256), lds, st, p);
     return lwdetr_check_launch();
 }
 
 template <typename T, int C, int TT>
 int launch_mlp(const MlpParams& p, hipStream_t st) {
-    return p.att ? launch_mlp_p<T, C, TT, true>(p, st) : launch_mlp_p<T, C, TT, false>(p, st);
+    if (p.att && p.wqkv) return launch_mlp_p<T, C, TT, true, true>(p, st);
+    if (p.att) return launch_mlp_p<T, C, TT, true, false>(p, st);
+    if (p.wqkv) return LWDETR_ERR_UNSUPPORTED;          // the chained QKV is only built together with the projection
+    return launch_mlp_p<T, C, TT, false, false>(p, st);
 }
 
 template <typename T, int TT16, int TT32>
@@ -332,13 +431,19 @@ int dispatch_c(const MlpParams& p, int C, hipStream_t st) {
 extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_folded, const void* w2_chunked,
                                 const float* b2, const float* gamma2, void* out2, long ld2, float* stats_out, long M,
                                 int C, float eps, float eps_next, const void* att, long ldatt, const void* wp,
-                                const float* bp, const float* gamma1, int dtype, void* hip_stream) {
+                                const float* bp, const float* gamma1, const void* wqkv_next, const float* bqkv_next,
+                                void* q_out, void* k_out, void* vt_out, float qscale, int heads, int hd, int Tp,
+                                int dtype, void* hip_stream) {
     if (!x || !w1_folded || !b1_folded || !w2_chunked || !b2 || !gamma2 || M < 0) return LWDETR_ERR_BAD_ARG;
     if (M == 0) return LWDETR_OK;
     if (ldx % 8 != 0 || (out2 && ld2 % 8 != 0)) return LWDETR_ERR_BAD_ARG;
     if (att && (!wp || !bp || !gamma1 || ldatt % 8 != 0)) return LWDETR_ERR_BAD_ARG;
     MlpParams p;
     p.att = att; p.ldatt = ldatt; p.wp = wp; p.bp = bp; p.gamma1 = gamma1;
+    p.wqkv = wqkv_next; p.bqkv = bqkv_next; p.q = q_out; p.k = k_out; p.vt = vt_out; p.qscale = qscale;
+    p.heads = heads; p.hd = hd; p.Tp = Tp;
+    if (wqkv_next && (!bqkv_next || !q_out || !k_out || !vt_out || heads <= 0 || hd % 4 != 0 || heads * hd != C || Tp % 4 != 0))
+        return LWDETR_ERR_BAD_ARG;
     p.x = x; p.ldx = ldx; p.w1 = w1_folded; p.b1 = b1_folded; p.w2p = w2_chunked; p.b2 = b2; p.gamma2 = gamma2;
     p.out2 = out2; p.ld2 = ld2; p.stats_out = stats_out; p.M = M; p.eps = eps; p.eps_next = eps_next;
     hipStream_t st = (hipStream_t)hip_stream;

@@ -177,14 +177,17 @@ class ForwardPlan:
             a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
         self.patch_op = ops[-1]
         qscale = K.attention_scale(hd)
+        fused = K.mlp_fused_supported(C, self.T)
         for i in range(self.depth):
             blk = f"{pre}.blocks.{i}"
             window = i in self.cfg.window_block_indexes
-            ops.append(LayerNormOp(self.x, pw.f(blk + ".norm1.weight"), pw.f(blk + ".norm1.bias"), xn, rows, C, 1e-6))
-            ops.append(GemmOp(xn, pw.w(blk + ".attn.qkv.weight"), rows, 3 * C, C, [
-                seg(q, 0, C, mode=OUT_HEADS, bias=pw.f(blk + ".attn.q_bias"), scale=qscale, p0=Tp, p1=hd, p2=heads),
-                seg(k, C, 2 * C, mode=OUT_HEADS, p0=Tp, p1=hd, p2=heads),
-                seg(vt, 2 * C, 3 * C, mode=OUT_HEADS_T, bias=pw.f(blk + ".attn.v_bias"), p0=Tp, p1=hd, p2=heads)]))
+            if i == 0 or not fused:
+                # norm1 + QKV as separate launches (blocks > 0 get them chained into the previous block's MLP kernel)
+                ops.append(LayerNormOp(self.x, pw.f(blk + ".norm1.weight"), pw.f(blk + ".norm1.bias"), xn, rows, C, 1e-6))
+                ops.append(GemmOp(xn, pw.w(blk + ".attn.qkv.weight"), rows, 3 * C, C, [
+                    seg(q, 0, C, mode=OUT_HEADS, bias=pw.f(blk + ".attn.q_bias"), scale=qscale, p0=Tp, p1=hd, p2=heads),
+                    seg(k, C, 2 * C, mode=OUT_HEADS, p0=Tp, p1=hd, p2=heads),
+                    seg(vt, 2 * C, 3 * C, mode=OUT_HEADS_T, bias=pw.f(blk + ".attn.v_bias"), p0=Tp, p1=hd, p2=heads)]))
             if window:
                 ops.append(AttnOp(q, k, vt, att, B=B, heads=heads, hd=hd, Tp=Tp, ldo=C, seqs_per_img=16,
                                   seq_tok_stride=self.Twp, keys_per_seq=self.Twp, sub_stride=self.Twp,
@@ -192,7 +195,6 @@ class ForwardPlan:
             else:
                 ops.append(AttnOp(q, k, vt, att, B=B, heads=heads, hd=hd, Tp=Tp, ldo=C, seqs_per_img=1,
                                   seq_tok_stride=Tp, keys_per_seq=Tp, sub_stride=self.Twp, sub_len=self.Tw, kind=1))
-            fused = K.mlp_fused_supported(C, self.T)
             if not fused:
                 ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
@@ -206,10 +208,17 @@ class ForwardPlan:
                 w1f, b1f, w2c = pw.custom_multi(blk + ".mlp.packed", lambda blk=blk: K.pack_mlp_weights(
                     pw.sd[blk + ".mlp.fc1.weight"], pw.sd[blk + ".mlp.fc1.bias"], pw.sd[blk + ".mlp.fc2.weight"],
                     pw.sd[blk + ".norm2.weight"], pw.sd[blk + ".norm2.bias"], self.T, proj=True))
+                nxt = {}
+                if i + 1 < self.depth:      # chain norm1 + QKV of block i+1 onto the rows this kernel just produced
+                    nb = f"{pre}.blocks.{i + 1}"
+                    wq, bq = pw.custom_multi(nb + ".qkv.packed", lambda nb=nb: K.pack_qkv_weights(
+                        pw.sd[nb + ".attn.qkv.weight"], pw.sd[nb + ".attn.q_bias"], pw.sd[nb + ".attn.v_bias"],
+                        pw.sd[nb + ".norm1.weight"], pw.sd[nb + ".norm1.bias"], self.T))
+                    nxt = dict(wqkv=wq, bqkv=bq, q=q, k=k, vt=vt, qscale=qscale, heads=heads, hd=hd, Tp=Tp)
                 ops.append(K.MlpFusedOp(self.x, w1f, b1f, w2c, pw.f(blk + ".mlp.fc2.bias"), pw.f(blk + ".gamma_2"), rows,
                                         C, 1e-6, out2=tap_out, ld2=ntap * C, att=att, ldatt=C,
                                         wp=pw.w(blk + ".attn.proj.weight"), bp=pw.f(blk + ".attn.proj.bias"),
-                                        gamma1=pw.f(blk + ".gamma_1")))
+                                        gamma1=pw.f(blk + ".gamma_1"), eps_next=1e-6, **nxt))
             else:
                 ops.append(LayerNormOp(self.x, pw.f(blk + ".norm2.weight"), pw.f(blk + ".norm2.bias"), xn, rows, C, 1e-6))
                 ops.append(GemmOp(xn, pw.w(blk + ".mlp.fc1.weight"), rows, 4 * C, C, [

@@ -143,19 +143,30 @@ def pack_mlp_weights(w1, b1, w2, ln_w, ln_b, dtype, proj=False):
     return w1f, b1f, w2c
 
 
+def pack_qkv_weights(wqkv, q_bias, v_bias, ln_w, ln_b, dtype):
+    """Next-block QKV for the chained form of lwdetr_mlp_fused: LayerNorm affine folded in, columns in k-slot order."""
+    wqkv, q_bias, v_bias, ln_w, ln_b = (t.float() for t in (wqkv, q_bias, v_bias, ln_w, ln_b))
+    c = wqkv.shape[1]
+    bias = torch.cat([q_bias, torch.zeros_like(q_bias), v_bias]) + wqkv @ ln_b
+    w = (wqkv * ln_w[None, :]).view(3 * c, c // 32, 32)[:, :, torch.tensor(_KSLOT_PERM)].reshape(3 * c, c)
+    return w.to(dtype).contiguous(), bias.contiguous()
+
+
 class MlpFusedOp:
     """x <- x + gamma2 * fc2(GELU(fc1(LN(x)))) in one launch (weights packed by ``pack_mlp_weights``)."""
 
     def __init__(self, x, w1f, b1f, w2c, b2, gamma2, M, C_, eps, *, ldx=None, out2=None, ld2=0, stats_out=None,
-                 eps_next=1e-6, att=None, ldatt=None, wp=None, bp=None, gamma1=None):
+                 eps_next=1e-6, att=None, ldatt=None, wp=None, bp=None, gamma1=None, wqkv=None, bqkv=None, q=None,
+                 k=None, vt=None, qscale=1.0, heads=0, hd=0, Tp=0):
         assert b1f.dtype == torch.float32 and b2.dtype == torch.float32 and gamma2.dtype == torch.float32
         assert w1f.dtype == x.dtype and w2c.dtype == x.dtype and w1f.is_contiguous() and w2c.is_contiguous()
         self.args = (_ptr(x), ldx if ldx is not None else C_, _ptr(w1f), _ptr(b1f), _ptr(w2c), _ptr(b2), _ptr(gamma2),
                      _ptr(out2), ld2, _ptr(stats_out), M, C_, float(eps), float(eps_next), _ptr(att),
-                     ldatt if ldatt is not None else C_, _ptr(wp), _ptr(bp), _ptr(gamma1), _nat.dtype_code(x.dtype))
+                     ldatt if ldatt is not None else C_, _ptr(wp), _ptr(bp), _ptr(gamma1), _ptr(wqkv), _ptr(bqkv),
+                     _ptr(q), _ptr(k), _ptr(vt), float(qscale), heads, hd, Tp, _nat.dtype_code(x.dtype))
         if att is not None:
             assert wp.dtype == x.dtype and wp.is_contiguous() and bp.dtype == torch.float32 and gamma1.dtype == torch.float32
-        self._keep = (x, w1f, b1f, w2c, b2, gamma2, out2, stats_out, att, wp, bp, gamma1)
+        self._keep = (x, w1f, b1f, w2c, b2, gamma2, out2, stats_out, att, wp, bp, gamma1, wqkv, bqkv, q, k, vt)
         self._fn = _nat.lib().lwdetr_mlp_fused
 
     def __call__(self, stream=None):

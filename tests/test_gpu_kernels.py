@@ -253,6 +253,28 @@ def test_mlp_fused(dtype, c, m):
     xx = x.clone()
     K.MlpFusedOp(xx, w1p, b1p, w2p, b2, g2, m, c, 1e-6, att=att, wp=wp.to(dtype).contiguous(), bp=bp, gamma1=g1)()
     assert _relerr(xx, ref2) < tol, _relerr(xx, ref2)
+    # ... and with the next block's LayerNorm + QKV chained behind it (Q / K head layout, V transposed)
+    heads, hd = 12, c // 12
+    tp = 100 if m % 100 == 0 else 4 * (m // 4 // 1) if False else None
+    tp = {1000: 100, 64: 64, 333: None}[m]
+    if tp is not None:
+        nb = m // tp
+        wqkv = _rand(3 * c, c, scale=c ** -0.5, seed=13)
+        qb, vb = _rand(c, seed=14) * 0.1, _rand(c, seed=15) * 0.1
+        lw1, lb1 = _rand(c, seed=16) * 0.2 + 1, _rand(c, seed=17) * 0.1
+        wq, bq = K.pack_qkv_weights(wqkv, qb, vb, lw1, lb1, dtype)
+        q = torch.zeros(nb, heads, tp, hd, dtype=dtype, device=_dev())
+        k = torch.zeros_like(q)
+        vt = torch.zeros(nb, heads, hd, tp, dtype=dtype, device=_dev())
+        xx2 = x.clone()
+        K.MlpFusedOp(xx2, w1p, b1p, w2p, b2, g2, m, c, 1e-6, att=att, wp=wp.to(dtype).contiguous(), bp=bp, gamma1=g1,
+                     wqkv=wq, bqkv=bq, q=q, k=k, vt=vt, qscale=0.37, heads=heads, hd=hd, Tp=tp)()
+        assert torch.equal(xx2, xx)
+        y = F.layer_norm(xx2.float(), (c,), lw1, lb1, 1e-6) @ wqkv.t() + torch.cat([qb, torch.zeros_like(qb), vb])
+        sp = lambda t_: t_.reshape(nb, tp, heads, hd).permute(0, 2, 1, 3)
+        assert _relerr(q, sp(y[:, :c]) * 0.37) < tol * 2
+        assert _relerr(k, sp(y[:, c:2 * c])) < tol * 2
+        assert _relerr(vt, sp(y[:, 2 * c:]).transpose(2, 3)) < tol * 2
 
 
 def test_gemm_rejects_bad_arguments():
