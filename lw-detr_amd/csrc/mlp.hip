@@ -5,7 +5,9 @@
 // HBM traffic per block drops from  read x, write LN(x), read LN(x), write h(4C), read h(4C), read x, write x
 // to  read x, write x  (+ weights through L2).
 //
-// Structure (256 threads = 4 waves; each wave owns 16*TT tokens, all four share the weight tiles in LDS):
+// Structure (512 threads = 8 waves = ONE workgroup per CU; each wave owns one tile of 16*TT tokens, all eight share the
+// weight tiles in LDS - the weights are re-streamed once per workgroup, and a CU can only pull ~10-12 B/clk through
+// its load path, so tokens-per-workgroup is what sets the streaming cost. Tiles are dealt evenly over <= #CU workgroups):
 //   prologue : wave loads its token rows as MFMA B-operand fragments (lane: token l15, 8 channels per k-chunk) and
 //              normalises them in registers (two-pass f32 statistics; LN's affine is folded into W1/b1 on the host).
 //   hidden loop over chunks of 32 hidden units, double-buffered LDS tiles W1c[32][C] and W2c[C][32] (chunk-major
@@ -26,6 +28,8 @@
 
 namespace {
 
+constexpr int NW = 8, NTHR = NW * 64;      // waves / threads per workgroup
+
 struct MlpParams {
     void* x; long ldx;                 // in/out (M, C)
     const void* w1; const float* b1;   // (4C, C) with LN gamma folded in, b1' = b1 + W1 beta
@@ -34,6 +38,7 @@ struct MlpParams {
     void* out2; long ld2;              // optional second destination
     float* stats_out;                  // optional (M, 2): mean, rstd of the updated rows (eps_next)
     long M; float eps, eps_next;
+    int ntiles;                        // token tiles (16*TT rows each) in total; gridDim.x workgroups share them evenly
     // optional fused attention output projection: x <- x + gamma1 * (att Wp^T + bp) before the MLP
     const void* att; long ldatt; const void* wp; const float* bp; const float* gamma1;
     // optional chained LayerNorm + QKV projection of the NEXT block on the updated rows (vit.py:199, :123-130)
@@ -41,7 +46,7 @@ struct MlpParams {
 };
 
 template <typename T, int C, int TT, bool PROJ, bool QKV>
-__global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpParams p) {
+__global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     constexpr int KC = C / 32;                 // k-chunks of step 1
@@ -59,7 +64,12 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const long m_wave = (long)blockIdx.x * (64 * TT) + wave * (16 * TT);
+    // this workgroup's contiguous run of tiles (sizes differ by at most one); waves beyond it run on clamped rows and
+    // store nothing (they still take part in the weight staging and barriers)
+    const int tb = p.ntiles / (int)gridDim.x, tr = p.ntiles % (int)gridDim.x;
+    const int my_tiles = tb + ((int)blockIdx.x < tr ? 1 : 0);
+    const int tile0 = (int)blockIdx.x * tb + ((int)blockIdx.x < tr ? (int)blockIdx.x : tr);
+    const long m_wave = wave < my_tiles ? (long)(tile0 + wave) * (16 * TT) : p.M;
     T* __restrict__ X = (T*)p.x;
     const T* __restrict__ W1 = (const T*)p.w1;
     const T* __restrict__ W2 = (const T*)p.w2p;
@@ -73,16 +83,16 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
     constexpr int W1_INSTR = (W1_SLOTS + 63) / 64, W2_INSTR = (W2_SLOTS + 63) / 64;
     static_assert(W1_TILE % (64 * EPC) == 0 || true, "");
     // per-lane source offsets of every DMA piece this wave issues (chunk invariant; -1 = pad slot)
-    constexpr int W1_MY = (W1_INSTR + 3) / 4, W2_MY = (W2_INSTR + 3) / 4;
+    constexpr int W1_MY = (W1_INSTR + NW - 1) / NW, W2_MY = (W2_INSTR + NW - 1) / NW;
     int off1[W1_MY], off2[W2_MY];
 #pragma unroll
     for (int k = 0; k < W1_MY; ++k) {
-        const int slot = (wave + 4 * k) * 64 + lane, row = slot / W1_SLOTS_ROW, c = slot - row * W1_SLOTS_ROW;
+        const int slot = (wave + NW * k) * 64 + lane, row = slot / W1_SLOTS_ROW, c = slot - row * W1_SLOTS_ROW;
         off1[k] = (row < 32 && c < C / EPC) ? row * C + c * EPC : 0;
     }
 #pragma unroll
     for (int k = 0; k < W2_MY; ++k) {
-        const int slot = (wave + 4 * k) * 64 + lane, row = slot / W2_SLOTS_ROW, c = slot - row * W2_SLOTS_ROW;
+        const int slot = (wave + NW * k) * 64 + lane, row = slot / W2_SLOTS_ROW, c = slot - row * W2_SLOTS_ROW;
         off2[k] = (row < C && c < 32 / EPC) ? row * 32 + c * EPC : 0;
     }
     auto stage_w = [&](int hc, int buf) {
@@ -92,14 +102,14 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
         const T* s2 = W2 + (long)hc * 32 * C;
 #pragma unroll
         for (int k = 0; k < W1_MY; ++k) {
-            const int i = wave + 4 * k;
+            const int i = wave + NW * k;
             if (i < W1_INSTR)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + off1[k]),
                                                  (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < W2_MY; ++k) {
-            const int i = wave + 4 * k;
+            const int i = wave + NW * k;
             if (i < W2_INSTR)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s2 + off2[k]),
                                                  (__attribute__((address_space(3))) void*)(w2s + i * 64 * EPC), 16, 0, 0);
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
         T* w1s = smem + buf * TILE_STRIDE;
 #pragma unroll
         for (int k = 0; k < W1_MY; ++k) {
-            const int i = wave + 4 * k;
+            const int i = wave + NW * k;
             if (i < W1_INSTR)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off1[k]),
                                                  (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
@@ -119,11 +129,11 @@ __global__ __launch_bounds__(256, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpP
     // fc1 bias (and the projection's bias / LayerScale) -> LDS once: ordinary global loads inside the loops would force
     // an early drain of the DMA queue
     float* b1s = (float*)(smem + 2 * TILE_STRIDE);
-    for (int i = tid; i < HID; i += 256) b1s[i] = p.b1[i];
+    for (int i = tid; i < HID; i += NTHR) b1s[i] = p.b1[i];
     float* bps = b1s + HID;
-    if (PROJ) for (int i = tid; i < C; i += 256) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; }
+    if (PROJ) for (int i = tid; i < C; i += NTHR) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; }
     float* bqs = bps + 2 * C;
-    if (QKV) for (int i = tid; i < 3 * C; i += 256) bqs[i] = p.bqkv[i];
+    if (QKV) for (int i = tid; i < 3 * C; i += NTHR) bqs[i] = p.bqkv[i];
 
     // ---- prologue: token rows -> B-operand fragments xf (lane: token l15, 8 channels per k-chunk)
     V8 xf[TT][KC];
@@ -403,9 +413,19 @@ int launch_mlp_p(const MlpParams& p, hipStream_t st) {
             return LWDETR_ERR_LAUNCH;
         attr_done = true;
     }
-    const long blocks = (p.M + 64 * TT - 1) / (64 * TT);
-    ProfScope ps(KID_MLP, (16.0 + (PROJ ? 2.0 : 0.0) + (QKV ? 6.0 : 0.0)) * p.M * C * C, (double)p.M * C * sizeof(T) * (PROJ ? 3 : 2) + 8.0 * C * C * sizeof(T), st);
-    hipLaunchKernelGGL((mlp_kernel<T, C, TT, PROJ, QKV>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LWDETR_ERR_LAUNCH;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    MlpParams q = p;
+    q.ntiles = (int)((p.M + 16 * TT - 1) / (16 * TT));
+    long blocks = q.ntiles < ncu ? q.ntiles : ncu;                       // one workgroup per CU, tiles dealt evenly
+    if ((long)q.ntiles > blocks * NW) blocks = (q.ntiles + NW - 1) / NW;   // more than 8 tiles per CU: extra rounds
+    ProfScope ps(KID_MLP, (16.0 + (PROJ ? 2.0 : 0.0) + (QKV ? 6.0 : 0.0)) * p.M * C * C,
+                 (double)p.M * C * sizeof(T) * (PROJ ? 3 : 2) + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T), st);
+    hipLaunchKernelGGL((mlp_kernel<T, C, TT, PROJ, QKV>), dim3((unsigned)blocks), dim3(NTHR), lds, st, q);
     return lwdetr_check_launch();
 }
 
