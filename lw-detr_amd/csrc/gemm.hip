@@ -16,6 +16,7 @@
 //   COL  orientation: mfma(Xfrag, Wfrag) -> lane holds 4 consecutive m for one column n   (HEADS_T: V^T for attention)
 // Workgroup ids are remapped so that tiles sharing an A row-panel run on the same XCD (private L2).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -61,6 +62,129 @@ __device__ __forceinline__ void store_run(T* dst, const float* x, int cnt, bool 
         *(VT*)dst = o;
     } else {
         for (int e = 0; e < NV && e < cnt; ++e) dst[e] = from_f32<T>(x[e]);
+    }
+}
+
+// ---- shared epilogue: accumulators -> LDS (f32) -> fused bias / activation / scale / LayerScale / residual / masks ->
+// coalesced 16-byte stores in the destination layout of the tile's column segment.
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
+                                              f32x4 (&acc)[BN / 32][BM / 32], T* smem, long m0, int n0) {
+    constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
+    typedef typename Vec<T>::v8 V8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // ---- epilogue through LDS: accumulators are staged as f32 (64 tile rows per pass), then each thread finishes
+    // runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores, and the mode / activation logic
+    // lives in a small non-unrolled loop instead of being replicated per accumulator register.
+    float* stage = (float*)smem;
+    constexpr int SLD = BN + 4, SLD_T = 64 + 4;
+    const int n_end = sg.n_end < d.N ? sg.n_end : d.N;
+    T* __restrict__ out = (T*)sg.out;
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        if (BM == 64 || wm == pass) {
+            const int r0 = BM == 64 ? wm * WM : 0;          // first stage row of this wave
+            float* sp = col_orient ? stage + (wn * WN + l15) * SLD_T + r0 + g * 4 : stage + (r0 + l15) * SLD + wn * WN + g * 4;
+            const int fs = col_orient ? 16 * SLD_T : 16, ts = col_orient ? 16 : 16 * SLD;
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) *(f32x4*)(sp + f * fs + t * ts) = acc[f][t];
+        }
+        __syncthreads();
+        const long mbase = m0 + pass * 64;
+        if (!col_orient) {
+            // thread -> fixed 8-column run (col), rows strided by 256 / CPRW: column parameters are loop invariant and
+            // fetched with two 16-byte loads each (bias / gamma buffers are padded to a multiple of 8 floats by the host)
+            constexpr int CPRW = BN / 8, RSTEP = 256 / CPRW;
+            T* __restrict__ out2 = (T*)sg.out2;
+            const T* __restrict__ res = (const T*)sg.res;
+            const int col = (tid % CPRW) * 8, n = n0 + col;
+            if (n < n_end) {
+                const int nl = n - sg.n_begin, cnt = n_end - n < 8 ? n_end - n : 8;
+                float bv[8], gv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bv[e] = 0.f; gv[e] = 1.f; }
+                if (sg.bias) {
+                    const f32x4 b0 = *(const f32x4*)(sg.bias + nl), b1 = *(const f32x4*)(sg.bias + nl + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                }
+                if (sg.gamma) {
+                    const f32x4 g0 = *(const f32x4*)(sg.gamma + nl), g1 = *(const f32x4*)(sg.gamma + nl + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gv[e] = g0[e]; gv[4 + e] = g1[e]; }
+                }
+                const long coff = col_offset(sg, nl);
+                const int act = sg.act;
+                const float scale = sg.scale;
+#pragma unroll
+                for (int it = 0; it < 64 / RSTEP; ++it) {
+                    const int row = tid / CPRW + it * RSTEP;
+                    const long m = mbase + row;
+                    long roff;
+                    if (m >= d.M || !row_offset(sg, m, roff)) continue;
+                    bool keep_acc = true, keep_out = true;
+                    if (sg.rowmask) {
+                        const bool rm = sg.rowmask[m] != 0;
+                        keep_acc = rm || sg.rowmask_after; keep_out = rm || !sg.rowmask_after;
+                    }
+                    float x[8];
+                    {
+                        const f32x4 a0 = *(const f32x4*)(stage + row * SLD + col);
+                        const f32x4 a1 = *(const f32x4*)(stage + row * SLD + col + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { x[e] = keep_acc ? a0[e] : 0.f; x[4 + e] = keep_acc ? a1[e] : 0.f; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += bv[e];
+                    if (act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = act_apply<T>(x[e], act);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = x[e] * scale * gv[e];
+                    if (res) {
+                        const T* rp = res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl;
+                        if (cnt == 8 && ((size_t)rp & 15) == 0) {
+                            const V8 rv = *(const V8*)rp;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(rv[e]);
+                        } else {
+                            for (int e = 0; e < cnt; ++e) x[e] += to_f32<T>(rp[e]);
+                        }
+                    }
+                    if (!keep_out) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+                    }
+                    T* dst = out + roff + coff;
+                    store_run<T, 8>(dst, x, cnt, ((size_t)dst & 15) == 0);
+                    if (out2) { T* d2 = out2 + m * sg.ld2 + nl; store_run<T, 8>(d2, x, cnt, ((size_t)d2 & 15) == 0); }
+                }
+            }
+        } else {
+            // HEADS_T: out[((b*heads+h)*hd+dd)*Tp + t]: runs of 4 consecutive tokens of one output column
+            constexpr int RPC = 64 / 4;
+#pragma unroll 1
+            for (int c = tid; c < BN * RPC; c += 256) {
+                const int coln = c / RPC, row = (c - coln * RPC) * 4;
+                const long m = mbase + row;
+                const int n = n0 + coln;
+                if (m >= d.M || n >= n_end) continue;
+                const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
+                const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
+                const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, sg.act) * sg.scale;
+                const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
+                T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
+                store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -221,117 +345,147 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
         __syncthreads();
     }
 
-    // ---- epilogue through LDS: accumulators are staged as f32 (64 tile rows per pass), then each thread finishes
-    // runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores, and the mode / activation logic
-    // lives in a small non-unrolled loop instead of being replicated per accumulator register.
-    float* stage = (float*)smem;
-    constexpr int SLD = BN + 4, SLD_T = 64 + 4;
-    const int n_end = sg.n_end < d.N ? sg.n_end : d.N;
-    T* __restrict__ out = (T*)sg.out;
-    for (int pass = 0; pass < BM / 64; ++pass) {
-        if (BM == 64 || wm == pass) {
-            const int r0 = BM == 64 ? wm * WM : 0;          // first stage row of this wave
-            float* sp = col_orient ? stage + (wn * WN + l15) * SLD_T + r0 + g * 4 : stage + (r0 + l15) * SLD + wn * WN + g * 4;
-            const int fs = col_orient ? 16 * SLD_T : 16, ts = col_orient ? 16 : 16 * SLD;
+    gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, smem, m0, n0);
+}
+
+// ---- DMA-staged, multi-stage variant (16-bit types, no A2): operand tiles go global -> LDS with global_load_lds (no
+// staging registers, no ds_write pass) through an NST-deep ring of BK = 32 stages, NST-1 tiles in flight: counted
+// s_waitcnt vmcnt + raw s_barrier keep the prefetches alive across barriers (a __syncthreads would drain them). Every
+// wave issues the same number of DMA pieces per tile (dummy pieces read a zero page past the end of K), so the wait
+// count is a compile-time constant. The LDS image is unpadded with an XOR swizzle (16-byte slot c of row r lives at
+// slot c ^ ((r >> 1) & 3)) - conflict-free for the 16-lane ds_read_b128 service groups; a DMA piece is lane-linear in
+// LDS, so the swizzle is applied to the SOURCE address.
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];      // zero page: source of masked (out-of-range) lanes
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int AMODE, int NST>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d) {
+    constexpr int EPC = 8;
+    constexpr int A_MY = BM / 16 / 4, B_MY = BN / 16 / 4;        // DMA pieces (64 slots = 16 rows) per wave and operand
+    constexpr int PER_TILE = A_MY + B_MY;
+    constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
+    constexpr int STAGE = (BM + BN) * BK;
+    typedef typename Vec<T>::v8 V8;
+    static_assert(sizeof(T) == 2, "DMA variant is instantiated for f16 / bf16");
+    constexpr int LDS_ELEMS = NST * STAGE > 64 * (BN + 4) * 2 ? NST * STAGE : 64 * (BN + 4) * 2;   // ring, or f32 staging
+    __shared__ __attribute__((aligned(16))) T smem[LDS_ELEMS];
+
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const T* __restrict__ A = (const T*)d.A;
+    const T* __restrict__ W = (const T*)d.W;
+    const T* zero = (const T*)g_zero16;
+
+    // lane -> (row inside a 16-row piece, logical 16-byte column); the swizzle makes the column lane-constant
+    const int prow = lane >> 2, ccol = ((lane & 3) ^ ((lane >> 3) & 3)) * EPC;
+    const T* a_src[A_MY]; int a_b[A_MY], a_y[A_MY], a_x[A_MY];
+#pragma unroll
+    for (int k = 0; k < A_MY; ++k) {
+        const long m = m0 + 16 * (wave + 4 * k) + prow;
+        a_src[k] = nullptr; a_b[k] = -1; a_y[k] = 0; a_x[k] = 0;
+        if (m < d.M) {
+            if (AMODE == LWDETR_A_PLAIN) a_src[k] = A + m * d.lda + ccol;
+            else if (AMODE == LWDETR_A_CONV3x3) {
+                const int hw = d.conv_hout * d.conv_wout;
+                const int b = (int)(m / hw), r = (int)(m - (long)b * hw);
+                a_b[k] = b; a_y[k] = r / d.conv_wout; a_x[k] = r - a_y[k] * d.conv_wout;
+            } else {
+                const TokPos tp = tok_decode(m, d.a_tok);
+                if (tp.valid) { a_b[k] = tp.b; a_y[k] = tp.y; a_x[k] = tp.x; }
+            }
+        }
+    }
+    const T* w_src[B_MY];
+#pragma unroll
+    for (int k = 0; k < B_MY; ++k) {
+        const int n = n0 + 16 * (wave + 4 * k) + prow;
+        w_src[k] = n < d.N ? W + (long)n * d.K + ccol : nullptr;
+    }
+    const int nk = d.K / BK;
+    auto stage = [&](int kt) {           // always PER_TILE pieces; tiles past the end of K read the zero page
+        T* As = smem + (kt % NST) * STAGE;
+        T* Bs = As + BM * BK;
+        const int k0 = kt * BK;
+        const bool live = kt < nk;
+#pragma unroll
+        for (int k = 0; k < A_MY; ++k) {
+            const T* src = zero;
+            if (AMODE == LWDETR_A_PLAIN) {
+                if (live && a_src[k]) src = a_src[k] + k0;
+            } else if (AMODE == LWDETR_A_CONV3x3) {
+                const int tap = k0 / d.conv_cin;                    // uniform: Cin % 32 == 0
+                const int ci = k0 - tap * d.conv_cin + ccol;
+                const int iy = a_y[k] * d.conv_stride + tap / 3 - 1, ix = a_x[k] * d.conv_stride + tap % 3 - 1;
+                if (live && a_b[k] >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp)
+                    src = A + tok_encode(a_b[k], iy, ix, d.a_tok) * d.lda + d.a_col0 + ci;
+            } else {
+                const int kk = k0 + ccol, ch = kk >> 8, py = (kk >> 4) & 15, px = kk & 15;
+                if (live && a_b[k] >= 0)
+                    src = A + (((long)a_b[k] * 3 + ch) * d.img_h + a_y[k] * 16 + py) * d.img_w + a_x[k] * 16 + px;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(As + (wave + 4 * k) * 64 * EPC), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < B_MY; ++k) {
+            const T* src = (live && w_src[k]) ? w_src[k] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Bs + (wave + 4 * k) * 64 * EPC), 16, 0, 0);
+        }
+    };
+
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 3; ++s) if (s < d.nseg && n0 >= d.seg[s].n_begin) si = s;
+    const lwdetr_gemm_seg& sg = d.seg[si];
+    const bool col_orient = sg.mode == LWDETR_OUT_HEADS_T;
+
+    f32x4 acc[FT][TT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int pc = (g ^ ((l15 >> 1) & 3)) * EPC;       // swizzled slot of this lane's k-run
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) stage(s);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt<(NST - 2) * PER_TILE>();            // tile kt has landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody also left tile kt-1's buffer
+        stage(kt + NST - 1);                           // refill the buffer tile kt-1 used
+        const T* As = smem + (kt % NST) * STAGE;
+        const T* Bs = As + BM * BK;
+        V8 xf[TT], wf[FT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) xf[t] = *(const V8*)(As + (wm * WM + t * 16 + l15) * BK + pc);
+#pragma unroll
+        for (int f = 0; f < FT; ++f) wf[f] = *(const V8*)(Bs + (wn * WN + f * 16 + l15) * BK + pc);
+        if (!col_orient) {
 #pragma unroll
             for (int f = 0; f < FT; ++f)
 #pragma unroll
-                for (int t = 0; t < TT; ++t) *(f32x4*)(sp + f * fs + t * ts) = acc[f][t];
-        }
-        __syncthreads();
-        const long mbase = m0 + pass * 64;
-        if (!col_orient) {
-            // thread -> fixed 8-column run (col), rows strided by 256 / CPRW: column parameters are loop invariant and
-            // fetched with two 16-byte loads each (bias / gamma buffers are padded to a multiple of 8 floats by the host)
-            constexpr int CPRW = BN / 8, RSTEP = 256 / CPRW;
-            T* __restrict__ out2 = (T*)sg.out2;
-            const T* __restrict__ res = (const T*)sg.res;
-            const int col = (tid % CPRW) * 8, n = n0 + col;
-            if (n < n_end) {
-                const int nl = n - sg.n_begin, cnt = n_end - n < 8 ? n_end - n : 8;
-                float bv[8], gv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { bv[e] = 0.f; gv[e] = 1.f; }
-                if (sg.bias) {
-                    const f32x4 b0 = *(const f32x4*)(sg.bias + nl), b1 = *(const f32x4*)(sg.bias + nl + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-                }
-                if (sg.gamma) {
-                    const f32x4 g0 = *(const f32x4*)(sg.gamma + nl), g1 = *(const f32x4*)(sg.gamma + nl + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { gv[e] = g0[e]; gv[4 + e] = g1[e]; }
-                }
-                const long coff = col_offset(sg, nl);
-                const int act = sg.act;
-                const float scale = sg.scale;
-#pragma unroll
-                for (int it = 0; it < 64 / RSTEP; ++it) {
-                    const int row = tid / CPRW + it * RSTEP;
-                    const long m = mbase + row;
-                    long roff;
-                    if (m >= d.M || !row_offset(sg, m, roff)) continue;
-                    bool keep_acc = true, keep_out = true;
-                    if (sg.rowmask) {
-                        const bool rm = sg.rowmask[m] != 0;
-                        keep_acc = rm || sg.rowmask_after; keep_out = rm || !sg.rowmask_after;
-                    }
-                    float x[8];
-                    {
-                        const f32x4 a0 = *(const f32x4*)(stage + row * SLD + col);
-                        const f32x4 a1 = *(const f32x4*)(stage + row * SLD + col + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { x[e] = keep_acc ? a0[e] : 0.f; x[4 + e] = keep_acc ? a1[e] : 0.f; }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] += bv[e];
-                    if (act != ACT_NONE) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = act_apply<T>(x[e], act);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = x[e] * scale * gv[e];
-                    if (res) {
-                        const T* rp = res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl;
-                        if (cnt == 8 && ((size_t)rp & 15) == 0) {
-                            const V8 rv = *(const V8*)rp;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(rv[e]);
-                        } else {
-                            for (int e = 0; e < cnt; ++e) x[e] += to_f32<T>(rp[e]);
-                        }
-                    }
-                    if (!keep_out) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = 0.f;
-                    }
-                    T* dst = out + roff + coff;
-                    store_run<T, 8>(dst, x, cnt, ((size_t)dst & 15) == 0);
-                    if (out2) { T* d2 = out2 + m * sg.ld2 + nl; store_run<T, 8>(d2, x, cnt, ((size_t)d2 & 15) == 0); }
-                }
-            }
+                for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(wf[f], xf[t], acc[f][t]);
         } else {
-            // HEADS_T: out[((b*heads+h)*hd+dd)*Tp + t]: runs of 4 consecutive tokens of one output column
-            constexpr int RPC = 64 / 4;
-#pragma unroll 1
-            for (int c = tid; c < BN * RPC; c += 256) {
-                const int coln = c / RPC, row = (c - coln * RPC) * 4;
-                const long m = mbase + row;
-                const int n = n0 + coln;
-                if (m >= d.M || n >= n_end) continue;
-                const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
-                const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
-                const float bias = sg.bias ? sg.bias[nl] : 0.f;
-                float x[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, sg.act) * sg.scale;
-                const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
-                T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
-                store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
-            }
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(xf[t], wf[f], acc[f][t]);
         }
-        __syncthreads();
     }
+    __syncthreads();            // drains the dummy tail pieces and the last fragment reads before LDS is re-used
+    gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, smem, m0, n0);
 }
 
 template <typename T, int AMODE>
@@ -352,6 +506,17 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     if (nwg <= 0 || nwg > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
     const int kid = AMODE == LWDETR_A_PLAIN ? KID_GEMM : (AMODE == LWDETR_A_CONV3x3 ? KID_GEMM_CONV : KID_GEMM_PATCH);
     ProfScope ps(kid, 2.0 * d.M * d.N * d.K, ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) * sizeof(T), st);
+    if constexpr (sizeof(T) == 2) {
+        static const char* env = getenv("LWDETR_GEMM_DMA");
+        const int mode = env ? atoi(env) : 3;
+        if (mode && !d.A2) {
+            if (small) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            else if (bn64) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            else if (mode == 4) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, AMODE, 3>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            return lwdetr_check_launch();
+        }
+    }
     if (small) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
     else if (bn64) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AMODE>), dim3((unsigned)nwg), dim3(256), 0, st, d);
     else if constexpr (sizeof(T) == 2)
