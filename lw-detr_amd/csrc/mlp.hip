@@ -128,7 +128,8 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     };
     // fc1 bias (and the projection's bias / LayerScale) -> LDS once: ordinary global loads inside the loops would force
     // an early drain of the DMA queue
-    float* b1s = (float*)(smem + 2 * TILE_STRIDE);
+    constexpr int XCHG = QKV ? NW * 16 * TT * (C + 2 * EPC) : 0;
+    float* b1s = (float*)(smem + (2 * TILE_STRIDE > XCHG ? 2 * TILE_STRIDE : XCHG));
     for (int i = tid; i < HID; i += NTHR) b1s[i] = p.b1[i];
     float* bps = b1s + HID;
     if (PROJ) for (int i = tid; i < C; i += NTHR) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; }
@@ -271,7 +272,6 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     }
 
     // ---- epilogue: lane holds channels n*16 + 4g .. +3 of token l15
-    if (QKV) stage_rows32((const T*)p.wqkv, 0);          // first QKV weight piece streams in under the epilogue
     T* __restrict__ O2 = (T*)p.out2;
     V8 xq[QKV ? TT : 1][QKV ? KC : 1];
 #pragma unroll
@@ -323,80 +323,85 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
         }
     }
     if (QKV) {
-        // ---- chained LayerNorm + QKV of the next block: 3C/32 pieces of 32 output features through the W1 buffers.
+        // ---- chained LayerNorm + QKV of the next block, re-partitioned: the normalised rows of ALL tiles of the
+        // workgroup are exchanged through LDS, and each wave keeps ITS share of the QKV weight (every 8th 16-feature
+        // tile, A-stationary in registers, fetched once straight from L2) and sweeps the workgroup's tokens. No weight
+        // streaming, no per-piece DMA latency chain, one barrier.
         // Q, K: D[feature][token] (lane: 4 consecutive features of a head, token l15) -> (B, heads, Tp, hd);
         // V   : operands swapped, D[token][feature] (lane: 4 consecutive tokens, feature l15) -> V^T (B, heads, hd, Tp).
+        constexpr int XLD = C + 2 * EPC;                  // row stride == 2 (mod 4) slots: conflict-free fragment reads
+        constexpr int NTQ = 3 * C / 16, NJ = (NTQ + NW - 1) / NW;
         const T* __restrict__ WQ = (const T*)p.wqkv;
         T* __restrict__ Qo = (T*)p.q; T* __restrict__ Ko = (T*)p.k; T* __restrict__ Vo = (T*)p.vt;
-        constexpr int NP = 3 * C / 32, PSEG = C / 32;
+        constexpr int FRAG_REGS = KC * (int)sizeof(V8) / 4;
+        constexpr int JP = (120 / FRAG_REGS) < 1 ? 1 : ((120 / FRAG_REGS) > NJ ? NJ : (120 / FRAG_REGS));   // tiles per pass
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                *(V8*)(smem + ((wave * TT + t) * 16 + l15) * XLD + kc * 32 + g * 8) = xq[t][kc];
         __syncthreads();
+        const long m_blk = (long)tile0 * (16 * TT);
+        const int ntt = my_tiles * TT;                    // 16-token tiles that carry real rows
 #pragma unroll 1
-        for (int pc = 0; pc < NP; ++pc) {
-            const int buf = pc & 1;
-            if (pc + 1 < NP) stage_rows32(WQ + (long)(pc + 1) * 32 * C, buf ^ 1);
-            const T* ws = smem + buf * TILE_STRIDE;
-            const int sg = pc / PSEG;                      // 0 q, 1 k, 2 v
-            f32x4 acc[2][TT];
+        for (int j0 = 0; j0 < NJ; j0 += JP) {
+            V8 wq[JP][KC];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < JP; ++j) {
+                const int nt = wave + NW * (j0 + j);
+                const T* wr = WQ + (long)((nt < NTQ ? nt : NTQ - 1) * 16 + l15) * C + g * 8;
 #pragma unroll
-                for (int t = 0; t < TT; ++t) acc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (sg < 2) {
-#pragma unroll
-                for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const V8 a = *(const V8*)(ws + (h * 16 + l15) * W1_LD + kc * 32 + g * 8);
-#pragma unroll
-                        for (int t = 0; t < TT; ++t) acc[h][t] = Mma<T>::k32(a, xq[t][kc], acc[h][t]);
-                    }
-            } else {
-#pragma unroll
-                for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const V8 a = *(const V8*)(ws + (h * 16 + l15) * W1_LD + kc * 32 + g * 8);
-#pragma unroll
-                        for (int t = 0; t < TT; ++t) acc[h][t] = Mma<T>::k32(xq[t][kc], a, acc[h][t]);
-                    }
+                for (int kc = 0; kc < KC; ++kc) wq[j][kc] = *(const V8*)(wr + kc * 32);
             }
-            if (sg < 2) {
-                T* __restrict__ dst = sg == 0 ? Qo : Ko;
-                const float sc = sg == 0 ? p.qscale : 1.f;
+            // destination offsets split into a per-tile-column part (here, once per pass) and a per-token part (once per
+            // token tile): no integer division inside the MFMA loop
+            long coff[JP]; float4 cbias[JP]; int csg[JP];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int nl = (pc - sg * PSEG) * 32 + h * 16 + g * 4;          // feature inside the segment
+            for (int j = 0; j < JP; ++j) {
+                const int nt = wave + NW * (j0 + j);
+                const int ntc = nt < NTQ ? nt : NTQ - 1;
+                const int sg = ntc / (C / 16), nl0 = (ntc - sg * (C / 16)) * 16;
+                csg[j] = nt < NTQ ? sg : -1;
+                if (sg < 2) {
+                    const int nl = nl0 + g * 4, hh = nl / p.hd, dd = nl - hh * p.hd;
+                    coff[j] = (long)hh * p.Tp * p.hd + dd;
                     const f32x4 bb = *(const f32x4*)(bqs + sg * C + nl);
-                    const int hh = nl / p.hd, dd = nl - hh * p.hd;
-#pragma unroll
-                    for (int t = 0; t < TT; ++t) {
-                        const long m = m_wave + t * 16 + l15;
-                        if (m < p.M) {
-                            const long b = m / p.Tp, tk = m - b * p.Tp;
-                            *(V4*)(dst + ((b * p.heads + hh) * p.Tp + tk) * p.hd + dd) = cvt4<T>((acc[h][t] + bb) * sc);
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int nl = (pc - 2 * PSEG) * 32 + h * 16 + l15;
+                    cbias[j] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+                } else {
+                    const int nl = nl0 + l15, hh = nl / p.hd, dd = nl - hh * p.hd;
+                    coff[j] = ((long)hh * p.hd + dd) * p.Tp;
                     const float bb = bqs[2 * C + nl];
-                    const int hh = nl / p.hd, dd = nl - hh * p.hd;
+                    cbias[j] = make_float4(bb, bb, bb, bb);
+                }
+            }
+#pragma unroll 1
+            for (int tt = 0; tt < ntt; ++tt) {
+                V8 xr[KC];
 #pragma unroll
-                    for (int t = 0; t < TT; ++t) {
-                        const long m = m_wave + t * 16 + g * 4;
-                        if (m < p.M) {
-                            const long b = m / p.Tp, tk = m - b * p.Tp;
-                            T* dp = Vo + ((b * p.heads + hh) * p.hd + dd) * p.Tp + tk;
-                            const V4 o = cvt4<T>(acc[h][t] + bb);
-                            if (m + 3 < p.M) *(V4*)dp = o;
-                            else for (int e = 0; e < 4; ++e) if (m + e < p.M) dp[e] = o[e];
+                for (int kc = 0; kc < KC; ++kc) xr[kc] = *(const V8*)(smem + (tt * 16 + l15) * XLD + kc * 32 + g * 8);
+                const int mq = (int)m_blk + tt * 16 + l15, mv = (int)m_blk + tt * 16 + g * 4;
+                const int bq_ = mq / p.Tp, bv_ = mv / p.Tp;
+                const long roff_qk = ((long)bq_ * p.heads * p.Tp + (mq - bq_ * p.Tp)) * p.hd;
+                const long roff_v = (long)bv_ * p.heads * p.hd * p.Tp + (mv - bv_ * p.Tp);
+                const bool okq = mq < p.M, okv = mv < p.M;
+#pragma unroll
+                for (int j = 0; j < JP; ++j) {
+                    if (csg[j] < 0) continue;
+                    f32x4 acc = {cbias[j].x, cbias[j].y, cbias[j].z, cbias[j].w};
+                    if (csg[j] < 2) {
+#pragma unroll
+                        for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(wq[j][kc], xr[kc], acc);
+                        if (okq) {
+                            T* dst = csg[j] == 0 ? Qo : Ko;
+                            *(V4*)(dst + roff_qk + coff[j]) = cvt4<T>(acc * (csg[j] == 0 ? p.qscale : 1.f));
                         }
+                    } else {
+#pragma unroll
+                        for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(xr[kc], wq[j][kc], acc);
+                        if (okv) *(V4*)(Vo + roff_v + coff[j]) = cvt4<T>(acc);   // M, Tp multiples of 4: whole 4-token run
                     }
                 }
             }
-            __syncthreads();
         }
     }
 }
@@ -406,7 +411,9 @@ int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int PIECE = 64 * EPC;
     constexpr int W1P = (32 * (C + 2 * EPC) + PIECE - 1) / PIECE * PIECE, W2P = (C * (32 + 2 * EPC) + PIECE - 1) / PIECE * PIECE;
-    constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 9 * C * sizeof(float);
+    constexpr size_t tiles_b = 2 * (size_t)(W1P + W2P) * sizeof(T);
+    constexpr size_t xchg_b = QKV ? (size_t)NW * 16 * TT * (C + 2 * EPC) * sizeof(T) : 0;
+    constexpr size_t lds = (tiles_b > xchg_b ? tiles_b : xchg_b) + 9 * C * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -462,7 +469,8 @@ extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const 
     p.att = att; p.ldatt = ldatt; p.wp = wp; p.bp = bp; p.gamma1 = gamma1;
     p.wqkv = wqkv_next; p.bqkv = bqkv_next; p.q = q_out; p.k = k_out; p.vt = vt_out; p.qscale = qscale;
     p.heads = heads; p.hd = hd; p.Tp = Tp;
-    if (wqkv_next && (!bqkv_next || !q_out || !k_out || !vt_out || heads <= 0 || hd % 4 != 0 || heads * hd != C || Tp % 4 != 0))
+    if (wqkv_next && (!bqkv_next || !q_out || !k_out || !vt_out || heads <= 0 || hd % 4 != 0 || heads * hd != C || Tp % 4 != 0 ||
+                      M % 4 != 0))
         return LWDETR_ERR_BAD_ARG;
     p.x = x; p.ldx = ldx; p.w1 = w1_folded; p.b1 = b1_folded; p.w2p = w2_chunked; p.b2 = b2; p.gamma2 = gamma2;
     p.out2 = out2; p.ld2 = ld2; p.stats_out = stats_out; p.M = M; p.eps = eps; p.eps_next = eps_next;
