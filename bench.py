@@ -102,7 +102,7 @@ def main():
 
     def step():
         out = model(images)
-        s, l, b = pp.select(out["pred_logits"].float(), out["pred_boxes"].float(), sizes)
+        s, l, b = pp.select(out["pred_logits"], out["pred_boxes"], sizes)
         det = ldist.pack_detections(s, l, b)
         return ldist.all_gather_detections(det, gathered)
 
@@ -167,23 +167,37 @@ def main():
             ach = by / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4)}
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r1c_hbm_traffic.json")
+        if os.path.exists(tf) and (a.size, a.batch, a.res, a.dtype) == ("small", 32, 640, "fp16"):
+            traffic = json.load(open(tf)).get(name, {}).get("bytes_per_launch")      # rocprofv3 PMC pass of this workload
         roof.update({"kernel": name, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": v["count"],
-                     "alg_flops_per_launch": fl, "alg_bytes_per_launch": by, "traffic": None})
+                     "alg_flops_per_launch": fl, "alg_bytes_per_launch": by, "traffic": traffic})
         result["roofline"] = roof
         result["kernels"] = table
 
     if rank == 0 and a.latency:
         one = images[:1].contiguous()
-        lat = []
-        for i in range(60):
-            torch.cuda.synchronize(dev)
-            t = time.perf_counter()
-            model(one)
-            torch.cuda.synchronize(dev)
-            if i >= 10:
-                lat.append((time.perf_counter() - t) * 1e3)
-        lat.sort()
-        result["latency_bs1_ms"] = {"p50": round(lat[len(lat) // 2], 3), "p90": round(lat[int(len(lat) * 0.9)], 3)}
+
+        def p50p90(fn):
+            lat = []
+            for i in range(110):
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(dev)
+                if i >= 10:
+                    lat.append((time.perf_counter() - t) * 1e3)
+            lat.sort()
+            return {"p50": round(lat[len(lat) // 2], 3), "p90": round(lat[int(len(lat) * 0.9)], 3)}
+
+        # forward + PostProcess of one resident image: eager launches, then the same work replayed as one HIP graph
+        result["latency_bs1_ms"] = p50p90(lambda: pp.select(*(lambda o: (o["pred_logits"], o["pred_boxes"]))(model(one)), sizes[:1]))
+        try:
+            graphed = model.capture(one, postprocess=pp, target_sizes=sizes[:1])
+            result["latency_bs1_hipgraph_ms"] = p50p90(lambda: graphed(one))
+        except Exception as e:                                   # report, never hide: the eager number above stands
+            result["latency_bs1_hipgraph_ms"] = {"error": repr(e)[:200]}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (child process)")

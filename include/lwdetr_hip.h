@@ -155,6 +155,19 @@ int lwdetr_decoder_inputs(const void* enc_delta, const float* props_sel, const f
 /* out[r] = (delta_xy * ref_wh + ref_xy, exp(delta_wh) * ref_wh) with ref row r % ref_rows (no sigmoid: bbox_reparam). */
 int lwdetr_box_reparam(const void* delta, const float* ref, long ref_rows, void* out, long R, int dtype, void* hip_stream);
 
+/* ---- sorted top-k (one workgroup per image) and its two users -----------------------------------------------------
+ * Order: descending value, equal values by ascending index (torch.topk leaves tie order unspecified). N < 2^20, K <= 1024.
+ * lwdetr_rowmax : out[r] = max(x[r, 0:ncols]) in f32 - the class-max of the encoder logits (transformer.py:246).
+ * lwdetr_topk   : x (B,N) contiguous -> idx_out (B,K) int64 (+ val_out (B,K) f32 when non-NULL); replaces
+ *                 torch.topk(..., num_queries, dim=1) of the two-stage selection (transformer.py:247).
+ * lwdetr_postprocess : PostProcess.forward (models/lwdetr.py:509-540): logits (B,nq,ncls) and boxes (B,nq,4 cxcywh)
+ *                 contiguous in `dtype`, target_sizes (B,2) f32 rows (h,w) -> scores (B,K) f32 = sigmoid of the K largest
+ *                 logits, labels (B,K) int64 = flat index % ncls, out_boxes (B,K,4) f32 xyxy in pixels. ---- */
+int lwdetr_rowmax(const void* x, long ld, long rows, int ncols, float* out, int dtype, void* hip_stream);
+int lwdetr_topk(const void* x, int B, int N, int K, int64_t* idx_out, float* val_out, int dtype, void* hip_stream);
+int lwdetr_postprocess(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
+                       float* scores, int64_t* labels, float* out_boxes, int dtype, void* hip_stream);
+
 /* ---- profiling: per-kernel HIP-event timing on the launch stream (off by default) ------------------------------ */
 int lwdetr_prof_enable(int on);
 int lwdetr_prof_num_kernels(void);

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblwdetr_hip.so")
+# LWDETR_HIP_LIB: tuning builds of the same library (tools/); the product always loads the in-tree one
+LIB_PATH = os.environ.get("LWDETR_HIP_LIB") or os.path.join(_HERE, "liblwdetr_hip.so")
 _lib = None
 
 DT_F32, DT_F16, DT_BF16, DT_F64 = 0, 1, 2, 3
@@ -76,6 +77,9 @@ def lib():
         l.lwdetr_select_gather.argtypes = [vp, vp, lg, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         l.lwdetr_decoder_inputs.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
         l.lwdetr_box_reparam.argtypes = [vp, vp, lg, vp, lg, i, vp]
+        l.lwdetr_rowmax.argtypes = [vp, lg, lg, i, vp, i, vp]
+        l.lwdetr_topk.argtypes = [vp, i, i, i, vp, vp, i, vp]
+        l.lwdetr_postprocess.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp, i, vp]
         l.lwdetr_prof_enable.argtypes = [i]
         l.lwdetr_prof_num_kernels.argtypes = []
         l.lwdetr_prof_kernel_name.argtypes = [i]
@@ -83,7 +87,7 @@ def lib():
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
         for fn in ("lwdetr_msda_forward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
                    "lwdetr_layernorm", "lwdetr_mlp_fused", "lwdetr_select_gather", "lwdetr_decoder_inputs",
-                   "lwdetr_box_reparam", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
+                   "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int
         _lib = l
     return _lib

@@ -26,9 +26,36 @@
 #define MLP_WAVES_PER_SIMD 2
 #endif
 
+// Phase timing for kernel tuning (tools/mlp_timing.py builds a private copy with -DLWDETR_MLP_TIMING=1; never in the
+// product library): s_memtime stamps of every wave of workgroup 0 at the phase boundaries.
+#ifdef LWDETR_MLP_TIMING
+__device__ unsigned long long g_mlp_timing[8][16];
+#define TSTAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_mlp_timing[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int lwdetr_debug_mlp_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_timing), sizeof(g_mlp_timing)) == hipSuccess ? 0 : 1;
+}
+#else
+#define TSTAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int NW = 8, NTHR = NW * 64;      // waves / threads per workgroup
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes, lane l lands at lds_wave_base + 16 l; source = sbase + voff (bytes).
+// Issued through inline assembly on purpose: hipcc treats the builtin form as a FLAT access that may touch LDS, and while
+// one is pending every ds_read dependency is resolved with s_waitcnt lgkmcnt(0) - which serialises the fragment ring of
+// the hidden loop. The copies are drained by the explicit vmcnt(0) in dma_sync(); hipcc's own vmcnt bookkeeping for
+// ordinary loads stays conservative (the untracked pieces only make its counted waits wait longer).
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, const void* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void dma_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 
 struct MlpParams {
     void* x; long ldx;                 // in/out (M, C)
@@ -64,6 +91,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
+    TSTAMP(0);
     // this workgroup's contiguous run of tiles (sizes differ by at most one); waves beyond it run on clamped rows and
     // store nothing (they still take part in the weight staging and barriers)
     const int tb = p.ntiles / (int)gridDim.x, tr = p.ntiles % (int)gridDim.x;
@@ -84,16 +112,16 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     static_assert(W1_TILE % (64 * EPC) == 0 || true, "");
     // per-lane source offsets of every DMA piece this wave issues (chunk invariant; -1 = pad slot)
     constexpr int W1_MY = (W1_INSTR + NW - 1) / NW, W2_MY = (W2_INSTR + NW - 1) / NW;
-    int off1[W1_MY], off2[W2_MY];
+    unsigned off1[W1_MY], off2[W2_MY];        // BYTE offsets (saddr + 32-bit voffset addressing: one VGPR per piece)
 #pragma unroll
     for (int k = 0; k < W1_MY; ++k) {
         const int slot = (wave + NW * k) * 64 + lane, row = slot / W1_SLOTS_ROW, c = slot - row * W1_SLOTS_ROW;
-        off1[k] = (row < 32 && c < C / EPC) ? row * C + c * EPC : 0;
+        off1[k] = (row < 32 && c < C / EPC) ? (unsigned)((row * C + c * EPC) * sizeof(T)) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < W2_MY; ++k) {
         const int slot = (wave + NW * k) * 64 + lane, row = slot / W2_SLOTS_ROW, c = slot - row * W2_SLOTS_ROW;
-        off2[k] = (row < C && c < 32 / EPC) ? row * 32 + c * EPC : 0;
+        off2[k] = (row < C && c < 32 / EPC) ? (unsigned)((row * 32 + c * EPC) * sizeof(T)) : 0u;
     }
     auto stage_w = [&](int hc, int buf) {
         T* w1s = smem + buf * TILE_STRIDE;
@@ -104,15 +132,13 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
         for (int k = 0; k < W1_MY; ++k) {
             const int i = wave + NW * k;
             if (i < W1_INSTR)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s1 + off1[k]),
-                                                 (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
+                dma16(s1, off1[k], w1s + i * 64 * EPC);
         }
 #pragma unroll
         for (int k = 0; k < W2_MY; ++k) {
             const int i = wave + NW * k;
             if (i < W2_INSTR)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s2 + off2[k]),
-                                                 (__attribute__((address_space(3))) void*)(w2s + i * 64 * EPC), 16, 0, 0);
+                dma16(s2, off2[k], w2s + i * 64 * EPC);
         }
     };
     // a (32 rows x C) weight piece into the W1 slot of buffer `buf` (projection / QKV weights stream through it)
@@ -122,8 +148,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
         for (int k = 0; k < W1_MY; ++k) {
             const int i = wave + NW * k;
             if (i < W1_INSTR)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off1[k]),
-                                                 (__attribute__((address_space(3))) void*)(w1s + i * 64 * EPC), 16, 0, 0);
+                dma16(src, off1[k], w1s + i * 64 * EPC);
         }
     };
     // fc1 bias (and the projection's bias / LayerScale) -> LDS once: ordinary global loads inside the loops would force
@@ -163,7 +188,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) af[t][kc] = *(const V8*)(ar + kc * 32);
         }
-        __syncthreads();
+        dma_sync();
 #pragma unroll
         for (int pc = 0; pc < KC; ++pc) {
             const int buf = pc & 1;
@@ -197,9 +222,10 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
                     for (int e = 0; e < 4; ++e) xf[t][pc][h * 4 + e] = x1[e];
                 }
             }
-            __syncthreads();
+            dma_sync();
         }
     }
+    TSTAMP(1);
     // ---- LayerNorm in registers (two-pass f32 statistics; the affine part is folded into W1 / b1 on the host)
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
@@ -229,28 +255,42 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc2[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (!PROJ) __syncthreads();
+    if (!PROJ) dma_sync();
+    TSTAMP(2);
     for (int hc = 0; hc < NCH; ++hc) {
         const int buf = hc & 1;
         if (hc + 1 < NCH) stage_w(hc + 1, buf ^ 1);
         const T* w1s = smem + buf * TILE_STRIDE;
         const T* w2s = w1s + W1_TILE_PAD;
-        // bias of this lane's 8 hidden units: rows 4g..4g+3 of the two 16-row tiles
+        // bias of this lane's 8 hidden units (rows 4g..4g+3 of the two 16-row tiles): the accumulators start from it
         const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
+        // The 2*KC + NT weight fragments of the chunk are read through a ring RD deep: the read of fragment i + RD is
+        // issued before the MFMAs of fragment i, so an LDS round trip is never exposed (left alone, hipcc issues every
+        // ds_read right in front of its MFMAs and waits for it: ~100 exposed cycles per 34 cycles of MFMA).
+        // MI355X measurements behind this loop (tools/ubench/issue.hip): plain VALU does NOT execute in the shadow of an
+        // MFMA on the same SIMD, neither from the same wave nor from its partner (cycles add up: 17.5 per 16x16x32 MFMA
+        // + 2.6 per VALU); transcendentals and ds_reads do. So the loop is as fast as its instruction count allows, and
+        // software-pipelining GELU against the neighbouring chunks' MFMAs (tried: one stream, skewed halves, priorities)
+        // buys nothing.
+        constexpr int RD = 3, NF1 = 2 * KC, NF = NF1 + NT;
+        auto frag = [&](int i) -> V8 {
+            if (i < NF1) return *(const V8*)(w1s + ((i & 1) * 16 + l15) * W1_LD + (i >> 1) * 32 + g * 8);
+            return *(const V8*)(w2s + ((i - NF1) * 16 + l15) * W2_LD + g * 8);     // k-slot order pre-permuted on the host
+        };
+        V8 fr[RD];
+#pragma unroll
+        for (int i = 0; i < RD; ++i) fr[i] = frag(i);
         // ---- step 1
         f32x4 acc1[2][TT];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < TT; ++t) { acc1[0][t] = bia0; acc1[1][t] = bia1; }
 #pragma unroll
-            for (int t = 0; t < TT; ++t) acc1[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NF1; ++i) {
+            const V8 a = fr[i % RD];
+            fr[i % RD] = frag(i + RD);
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const V8 a = *(const V8*)(w1s + (h * 16 + l15) * W1_LD + kc * 32 + g * 8);
-#pragma unroll
-                for (int t = 0; t < TT; ++t) acc1[h][t] = Mma<T>::k32(a, xf[t][kc], acc1[h][t]);
-            }
+            for (int t = 0; t < TT; ++t) acc1[i & 1][t] = Mma<T>::k32(a, xf[t][i >> 1], acc1[i & 1][t]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- GELU on the accumulator layout -> B operand of step 2
         V8 hf[TT];
@@ -258,19 +298,24 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hf[t][e] = from_f32<T>(gelu_for<T>(acc1[0][t][e] + bia0[e]));
-                hf[t][4 + e] = from_f32<T>(gelu_for<T>(acc1[1][t][e] + bia1[e]));
+                hf[t][e] = from_f32<T>(gelu_for<T>(acc1[0][t][e]));
+                hf[t][4 + e] = from_f32<T>(gelu_for<T>(acc1[1][t][e]));
             }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- step 2
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const V8 a = *(const V8*)(w2s + (n * 16 + l15) * W2_LD + g * 8);   // k-slot order pre-permuted on the host
+            const int i = NF1 + n;
+            const V8 a = fr[i % RD];
+            if (i + RD < NF) fr[i % RD] = frag(i + RD);
 #pragma unroll
             for (int t = 0; t < TT; ++t) acc2[n][t] = Mma<T>::k32(a, hf[t], acc2[n][t]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();        // drains this chunk's DMA (vmcnt) and orders the buffer swap
+        dma_sync();             // drains this chunk's DMA (vmcnt) and orders the buffer swap
     }
 
+    TSTAMP(3);
     // ---- epilogue: lane holds channels n*16 + 4g .. +3 of token l15
     T* __restrict__ O2 = (T*)p.out2;
     V8 xq[QKV ? TT : 1][QKV ? KC : 1];
@@ -322,6 +367,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
             }
         }
     }
+    TSTAMP(4);
     if (QKV) {
         // ---- chained LayerNorm + QKV of the next block, re-partitioned: the normalised rows of ALL tiles of the
         // workgroup are exchanged through LDS, and each wave keeps ITS share of the QKV weight (every 8th 16-feature
@@ -341,6 +387,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
             for (int kc = 0; kc < KC; ++kc)
                 *(V8*)(smem + ((wave * TT + t) * 16 + l15) * XLD + kc * 32 + g * 8) = xq[t][kc];
         __syncthreads();
+        TSTAMP(5);
         const long m_blk = (long)tile0 * (16 * TT);
         const int ntt = my_tiles * TT;                    // 16-token tiles that carry real rows
 #pragma unroll 1
@@ -404,6 +451,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
             }
         }
     }
+    TSTAMP(6);
 }
 
 template <typename T, int C, int TT, bool PROJ, bool QKV>

@@ -1,0 +1,222 @@
+// Sorted top-k selection for gfx950, one 1024-thread workgroup per image, and the two places LW-DETR uses it:
+//   * two-stage query selection: class-max of the encoder logits (rowmax kernel) -> top-nq rows in descending order
+//     (reference models/transformer.py:246-248, torch.topk(enc_outputs_class.max(-1)[0], num_queries, dim=1))
+//   * PostProcess: top-num_select of sigmoid(logits) over nq x classes, labels = idx % C, boxes = idx // C gathered,
+//     cxcywh -> xyxy, scaled by the target size (reference models/lwdetr.py:509-540, util/box_ops.py:21-25)
+// Selection = MSB-first radix select (11-bit digits, LDS histograms) on a 52-bit composite
+//     comp = order_preserving_u32(value) << 20 | (0xFFFFF - index)
+// which is unique per element, so the selected SET and its ORDER are fully deterministic: descending value, equal
+// values by ascending index (torch.topk leaves the order of ties unspecified). The select stops as soon as the bin
+// holding the k-th element is taken whole (3 passes when the k-th value is not tied). The k winners are then ranked
+// against each other in LDS (k*k/1024 compares per thread) instead of sorted.
+#include "common.h"
+
+namespace {
+
+constexpr int TK_THREADS = 1024;
+constexpr int TK_MAXK = 1024;
+constexpr int TK_IDX_BITS = 20;
+constexpr unsigned TK_IDX_MASK = (1u << TK_IDX_BITS) - 1;
+
+__device__ __forceinline__ unsigned fkey(float f) {          // monotone float -> u32 (ascending)
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned long long tk_comp(const T* __restrict__ x, int i) {
+    return ((unsigned long long)fkey(to_f32<T>(x[i])) << TK_IDX_BITS) | (unsigned long long)(TK_IDX_MASK - (unsigned)i);
+}
+
+struct TopkShared {
+    unsigned hist[2048];
+    unsigned long long sel[TK_MAXK];
+    unsigned rank[TK_MAXK];
+    unsigned bstar, above, cnt, nsel;
+};
+
+// Leaves the k winners' composites in sh.sel[0..k) and their descending ranks in sh.rank[0..k). All threads call it.
+template <typename T>
+__device__ void topk_block(const T* __restrict__ x, int N, int K, TopkShared& sh) {
+    const int tid = threadIdx.x;
+    unsigned long long prefix = 0;          // digits decided so far (the high bits of the threshold composite)
+    unsigned rem = (unsigned)K;             // how many elements are still to be taken among those matching the prefix
+    unsigned long long thr = 0;
+    int top = 32 + TK_IDX_BITS;             // bits not yet decided
+    while (true) {
+        const int bits = top > 30 ? 11 : 10;            // 52 = 11 + 11 + 10 + 10 + 10
+        const int shift = top - bits;
+        const unsigned nb = 1u << bits;
+        for (int i = tid; i < 2048; i += TK_THREADS) sh.hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += TK_THREADS) {
+            const unsigned long long c = tk_comp<T>(x, i);
+            if ((c >> top) == prefix) atomicAdd(&sh.hist[(unsigned)(c >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                  // wave 0: lane l owns bins [l * per, (l + 1) * per)
+            const int per = (int)nb >> 6;
+            unsigned own = 0;
+            for (int j = 0; j < per; ++j) own += sh.hist[tid * per + ((j + tid) & (per - 1))];
+            unsigned s = own;                            // inclusive suffix sum over lanes (lane 63 = highest bins)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(s, o);
+                if (tid + o < 64) s += t;
+            }
+            const unsigned excl = s - own;
+            if (excl < rem && rem <= s) {
+                unsigned acc = excl;
+                for (int j = per - 1; j >= 0; --j) {
+                    const unsigned c = sh.hist[tid * per + j];
+                    if (acc + c >= rem) { sh.bstar = (unsigned)(tid * per + j); sh.above = acc; sh.cnt = c; break; }
+                    acc += c;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned bstar = sh.bstar, above = sh.above, cnt = sh.cnt;
+        rem -= above;
+        prefix = (prefix << bits) | bstar;
+        top = shift;
+        if (cnt == rem || top == 0) { thr = prefix << top; break; }     // the whole bin is taken: threshold found
+    }
+    if (tid == 0) sh.nsel = 0;
+    for (int i = tid; i < TK_MAXK; i += TK_THREADS) sh.rank[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += TK_THREADS) {
+        const unsigned long long c = tk_comp<T>(x, i);
+        if (c >= thr) {
+            const unsigned p = atomicAdd(&sh.nsel, 1u);
+            if (p < (unsigned)K) sh.sel[p] = c;
+        }
+    }
+    __syncthreads();
+    // rank = number of winners with a larger composite; `parts` threads share one winner's k compares
+    const int parts = TK_THREADS / K > 0 ? TK_THREADS / K : 1;
+    const int e = tid % K, p = tid / K;
+    if (p < parts) {
+        const unsigned long long mine = sh.sel[e];
+        const int j0 = (int)((long)K * p / parts), j1 = (int)((long)K * (p + 1) / parts);
+        unsigned r = 0;
+        for (int j = j0; j < j1; ++j) r += sh.sel[j] > mine ? 1u : 0u;
+        atomicAdd(&sh.rank[e], r);
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ x, int N, int K, int64_t* __restrict__ idx_out,
+                                                          float* __restrict__ val_out) {
+    __shared__ TopkShared sh;
+    const int b = blockIdx.x;
+    topk_block<T>(x + (long)b * N, N, K, sh);
+    const int tid = threadIdx.x;
+    if (tid < K) {
+        const unsigned long long c = sh.sel[tid];
+        const unsigned r = sh.rank[tid];
+        idx_out[(long)b * K + r] = (int64_t)(TK_IDX_MASK - (unsigned)(c & TK_IDX_MASK));
+        if (val_out) val_out[(long)b * K + r] = fkey_inv((unsigned)(c >> TK_IDX_BITS));
+    }
+}
+
+// PostProcess: sigmoid is monotone, so the top-k runs on the logits and only the k winners go through sigmoid.
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void postprocess_kernel(const T* __restrict__ logits, const T* __restrict__ boxes,
+                                                                 const float* __restrict__ sizes, int nq, int ncls, int K,
+                                                                 float* __restrict__ scores, int64_t* __restrict__ labels,
+                                                                 float* __restrict__ out_boxes) {
+    __shared__ TopkShared sh;
+    const int b = blockIdx.x;
+    const int N = nq * ncls;
+    topk_block<T>(logits + (long)b * N, N, K, sh);
+    const int tid = threadIdx.x;
+    if (tid < K) {
+        const unsigned long long c = sh.sel[tid];
+        const long o = (long)b * K + sh.rank[tid];
+        const int i = (int)(TK_IDX_MASK - (unsigned)(c & TK_IDX_MASK));
+        const int q = i / ncls;
+        const float v = fkey_inv((unsigned)(c >> TK_IDX_BITS));
+        scores[o] = to_f32<T>(from_f32<T>(1.f / (1.f + expf(-v))));        // sigmoid evaluated in f32, stored at T's precision
+        labels[o] = (int64_t)(i - q * ncls);
+        const T* bx = boxes + ((long)b * nq + q) * 4;
+        const float cx = to_f32<T>(bx[0]), cy = to_f32<T>(bx[1]);
+        const float w = fmaxf(to_f32<T>(bx[2]), 0.f), h = fmaxf(to_f32<T>(bx[3]), 0.f);
+        const float ih = sizes[b * 2], iw = sizes[b * 2 + 1];               // target_sizes rows are (h, w)
+        // corners are formed at T's precision (the reference computes them on the model-dtype tensor) and scaled in f32
+        out_boxes[o * 4 + 0] = to_f32<T>(from_f32<T>(cx - 0.5f * w)) * iw;
+        out_boxes[o * 4 + 1] = to_f32<T>(from_f32<T>(cy - 0.5f * h)) * ih;
+        out_boxes[o * 4 + 2] = to_f32<T>(from_f32<T>(cx + 0.5f * w)) * iw;
+        out_boxes[o * 4 + 3] = to_f32<T>(from_f32<T>(cy + 0.5f * h)) * ih;
+    }
+}
+
+// Row maximum over the first `ncols` entries of each row: 16 lanes per row, 4-element vector loads (ld % 4 == 0).
+template <typename T>
+__global__ __launch_bounds__(256) void rowmax_kernel(const T* __restrict__ x, long ld, long rows, int ncols, float* __restrict__ out) {
+    constexpr int EPC = 4;
+    typedef T VC __attribute__((ext_vector_type(EPC)));
+    const int lane16 = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    float m = -INFINITY;
+    if (row < rows) {
+        const T* xr = x + row * ld;
+        const int full = ncols / EPC;
+        for (int c = lane16; c < full; c += 16) {
+            const VC t = *(const VC*)(xr + c * EPC);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) m = fmaxf(m, to_f32<T>(t[e]));
+        }
+        for (int c = full * EPC + lane16; c < ncols; c += 16) m = fmaxf(m, to_f32<T>(xr[c]));
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (row < rows && lane16 == 0) out[row] = m;
+}
+
+}  // namespace
+
+#define LWDETR_DISPATCH_T(dtype, CALL)                 \
+    switch (dtype) {                                   \
+        case DT_F32: { typedef float TT; CALL; break; } \
+        case DT_F16: { typedef f16 TT; CALL; break; }   \
+        case DT_BF16: { typedef bf16 TT; CALL; break; } \
+        default: return LWDETR_ERR_UNSUPPORTED;        \
+    }
+
+extern "C" int lwdetr_rowmax(const void* x, long ld, long rows, int ncols, float* out, int dtype, void* hip_stream) {
+    if (!x || !out || rows < 0 || ncols <= 0 || ld < ncols) return LWDETR_ERR_BAD_ARG;
+    if (rows == 0) return LWDETR_OK;
+    if (ld % 4 || ((uintptr_t)x & 15)) return LWDETR_ERR_BAD_ARG;                // vector-aligned row starts
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_ELTWISE, 0.0, (double)rows * ncols * (dtype == DT_F32 ? 4 : 2), st);
+    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((rowmax_kernel<TT>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st,
+                                                (const TT*)x, ld, rows, ncols, out));
+    return lwdetr_check_launch();
+}
+
+extern "C" int lwdetr_topk(const void* x, int B, int N, int K, int64_t* idx_out, float* val_out, int dtype, void* hip_stream) {
+    if (!x || !idx_out || B < 0 || K <= 0 || K > N || K > TK_MAXK || N > (int)TK_IDX_MASK) return LWDETR_ERR_BAD_ARG;
+    if (B == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_ELTWISE, 0.0, (double)B * N * (dtype == DT_F32 ? 4 : 2), st);
+    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((topk_kernel<TT>), dim3(B), dim3(TK_THREADS), 0, st, (const TT*)x, N, K, idx_out,
+                                                val_out));
+    return lwdetr_check_launch();
+}
+
+extern "C" int lwdetr_postprocess(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
+                                  float* scores, int64_t* labels, float* out_boxes, int dtype, void* hip_stream) {
+    if (!logits || !boxes || !target_sizes || !scores || !labels || !out_boxes || B < 0 || nq <= 0 || ncls <= 0 || K <= 0 ||
+        K > TK_MAXK || (long)nq * ncls > (long)TK_IDX_MASK || K > nq * ncls)
+        return LWDETR_ERR_BAD_ARG;
+    if (B == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_ELTWISE, 0.0, (double)B * nq * ncls * (dtype == DT_F32 ? 4 : 2), st);
+    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((postprocess_kernel<TT>), dim3(B), dim3(TK_THREADS), 0, st, (const TT*)logits,
+                                                (const TT*)boxes, target_sizes, nq, ncls, K, scores, labels, out_boxes));
+    return lwdetr_check_launch();
+}

@@ -439,6 +439,9 @@ class ForwardPlan:
         self.op_gather = K.RawOp("lwdetr_select_gather", (
             ptr(self.om), ptr(self.enc_cls), self.ldc, ptr(self.props), ptr(self.topk_idx), ptr(self.om_sel),
             ptr(self.enc_logits_sel), ptr(self.props_sel), B, S, d, nq, self.ncls, code), keep=())
+        self.cls_max = f32(B, S)
+        self.op_rowmax = K.RawOp("lwdetr_rowmax", (ptr(self.enc_cls), self.ldc, B * S, self.ncls, ptr(self.cls_max), code), keep=())
+        self.op_topk = K.RawOp("lwdetr_topk", (ptr(self.cls_max), B, S, nq, ptr(self.topk_idx), None, 0), keep=())
         self.op_dec_inputs = K.RawOp("lwdetr_decoder_inputs", (
             ptr(self.enc_delta), ptr(self.props_sel), ptr(self.refpoint), ptr(self.vr), L, ptr(self.query_feat),
             ptr(self.dim_t), ptr(self.enc_boxes), ptr(self.ref), ptr(self.sine), ptr(self.xdec), B, nq, d, code), keep=())
@@ -518,9 +521,11 @@ class ForwardPlan:
         for op in self.ops_enc:
             op(stream)
         # ---- two-stage selection (group 0 only at inference, transformer.py:229-264)
-        cls_max = self.enc_cls.view(B, S, self.ldc)[:, :, :self.ncls].max(-1)[0].float()
-        topk = torch.topk(cls_max, nq, dim=1)[1] if forced_topk is None else forced_topk.to(self.dev)
-        self.topk_idx.copy_(topk)
+        if forced_topk is None:
+            self.op_rowmax(stream)
+            self.op_topk(stream)
+        else:
+            self.topk_idx.copy_(forced_topk)
         self.op_gather(stream)
         for op in self.ops_sel:
             op(stream)
@@ -536,7 +541,46 @@ class ForwardPlan:
             out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(cls[:-1], coord[:-1])]
         out["enc_outputs"] = {"pred_logits": self.enc_logits_sel.clone(), "pred_boxes": self.enc_boxes.clone()}
         if collect is not None:
-            collect.update({"topk_idx": topk, "enc.class_max": cls_max, "memory": self.memory.view(B, S, d).clone(),
+            if forced_topk is not None:
+                self.op_rowmax(stream)
+            collect.update({"topk_idx": self.topk_idx.clone(), "enc.class_max": self.cls_max.clone(), "memory": self.memory.view(B, S, d).clone(),
                             "taps_cat": self.taps_cat.clone(), "x": self.x.clone(), "hs": self.hs.clone(),
                             "om": self.om.view(B, S, d).clone()})
         return out
+
+
+class GraphedForward:
+    """One ForwardPlan captured into a HIP graph (see ``LWDETR.capture``). All kernels of the plan are launched on the
+    stream torch is capturing (``_native.stream_ptr``), so the graph holds the whole forward: ~130 launches at the cost
+    of one ``hipGraphLaunch``."""
+
+    def __init__(self, plan, images, postprocess=None, target_sizes=None):
+        self.plan, dev = plan, plan.dev
+        self.static_in = images.to(device=dev, dtype=plan.T).contiguous().clone()
+        self.sizes = None if target_sizes is None else target_sizes.to(device=dev, dtype=torch.float32).contiguous().clone()
+        self.post = postprocess
+
+        def body():
+            out = plan.run(self.static_in)
+            if self.post is not None:
+                return out, self.post.select(out["pred_logits"], out["pred_boxes"], self.sizes)
+            return out, None
+
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                       # warm-up off the capture: one-time setup, allocator
+                body()
+                body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out, self.det = body()
+
+    @torch.no_grad()
+    def __call__(self, images=None):
+        if images is not None and images.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(images)
+        self.graph.replay()
+        return self.out if self.det is None else (self.out, self.det)

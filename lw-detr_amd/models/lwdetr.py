@@ -98,6 +98,19 @@ class LWDETR(nn.Module):
         with torch.cuda.device(plan.dev):
             return plan.run(x, mask, forced_topk=_forced_topk, collect=_collect)
 
+    @torch.no_grad()
+    def capture(self, images, postprocess=None, target_sizes=None):
+        """HIP-graph the forward for one dense batch shape (the launch-bound bs=1 latency path; the reference reaches its
+        latency numbers through a TensorRT engine, ``deploy/benchmark.py``). ``images`` (B,3,H,W) fixes shape, device and
+        dtype. Returns ``GraphedForward``: ``g(images)`` copies the batch into the static input, replays the captured
+        launches and returns the output dict (static tensors, overwritten by the next replay); with ``postprocess``
+        (a ``PostProcess``) and ``target_sizes`` the detections are captured too and returned as
+        ``(scores, labels, boxes)``."""
+        from ..engine import GraphedForward
+        assert isinstance(images, torch.Tensor) and images.dim() == 4
+        b, _, h, w = images.shape
+        return GraphedForward(self._plan(b, h, w), images, postprocess, target_sizes)
+
     def export(self):
         """Export-mode forward of the reference (``lwdetr.py:103-109, 176-195``): tensor in, (coords, logits) out."""
         self._export = True
@@ -130,10 +143,15 @@ class PostProcess(nn.Module):
         logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
         assert len(logits) == len(target_sizes) and target_sizes.shape[1] == 2
         scores, labels, xyxy = self.select(logits, boxes, target_sizes)
+        scores = scores.to(logits.dtype)                # as the reference: sigmoid of the model-dtype logits
         return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, xyxy)]
 
     def select(self, logits, boxes, target_sizes):
-        """Batched form: (scores (B,K), labels (B,K) int64, boxes (B,K,4))."""
+        """Batched form: (scores (B,K), labels (B,K) int64, boxes (B,K,4) xyxy pixels). Tensors on the GPU go through the
+        fused HIP kernel (``lwdetr_postprocess``: radix top-k on the logits, sigmoid / box conversion of the K winners,
+        scores and boxes in f32); host tensors (the reference's CPU evaluation plumbing) use the tensor ops below."""
+        if logits.is_cuda:
+            return self._select_hip(logits, boxes, target_sizes)
         prob = logits.sigmoid()
         scores, idx = torch.topk(prob.view(logits.shape[0], -1), self.num_select, dim=1)
         box_idx = idx // logits.shape[2]
@@ -145,6 +163,23 @@ class PostProcess(nn.Module):
         img_h, img_w = target_sizes.unbind(1)
         xyxy = xyxy * torch.stack([img_w, img_h, img_w, img_h], dim=1)[:, None, :]
         return scores, labels, xyxy
+
+    def _select_hip(self, logits, boxes, target_sizes, out=None):
+        from .. import _native
+        b, nq, ncls = logits.shape
+        k, dev = self.num_select, logits.device
+        logits = logits.contiguous()
+        boxes = boxes.to(logits.dtype).contiguous()
+        sizes = target_sizes.to(device=dev, dtype=torch.float32).contiguous()
+        if out is None:
+            out = (torch.empty(b, k, dtype=torch.float32, device=dev), torch.empty(b, k, dtype=torch.int64, device=dev),
+                   torch.empty(b, k, 4, dtype=torch.float32, device=dev))
+        with torch.cuda.device(dev):
+            rc = _native.lib().lwdetr_postprocess(logits.data_ptr(), boxes.data_ptr(), sizes.data_ptr(), b, nq, ncls, k,
+                                                  out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                                  _native.dtype_code(logits.dtype), _native.stream_ptr(dev))
+        _native.check(rc, "lwdetr_postprocess")
+        return out
 
 
 def build(args):
