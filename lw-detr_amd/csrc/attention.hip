@@ -39,6 +39,12 @@ __device__ __forceinline__ float xor32_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// This file is compiled with -fno-honor-nans (Makefile): otherwise hipcc puts a v_max_f32 x, x canonicalisation in front of
+// every fmaxf operand that comes out of an MFMA (it cannot prove the value is not a signalling NaN) - ~15 instructions per
+// 8 scores instead of 4 v_max3. Plain VALU does not overlap the matrix pipe on this chip (tools/ubench/issue.hip), so
+// softmax instruction count is kernel time. Infinities stay honoured (the key mask is -inf).
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 template <typename T, int HD, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     typedef typename Vec<T>::v8 V8;
@@ -75,10 +81,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     // Accumulators: O^T tiles, and the softmax denominator as one extra MFMA against an all-ones A operand (every
     // register of lsum[t] then holds the full row sum of query l15: no VALU adds, no cross-lane reduction).
     f32x4 o[QT][DT], lsum[QT];
-    float m_run[QT];            // exponent reference of each query (log2 domain); scores enter the MFMA as C = -m_run
+    // exponent reference of each query (log2 domain), kept negated and replicated: it is the C operand of every score
+    // MFMA as it stands (no per-tile broadcast moves), and only changes in the rare rescale path
+    f32x4 negm[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m_run[t] = 0.f; lsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        negm[t] = f32x4{0.f, 0.f, 0.f, 0.f}; lsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -123,8 +131,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                const float nm = -m_run[t];
-                f32x4 a = {nm, nm, nm, nm};
+                f32x4 a = negm[t];
                 if (HD >= 32) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) a = Mma<T>::k32(f.k8[kt][c], q8[t][c], a);
@@ -151,20 +158,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
         // ---- lazy online softmax: the reference only moves when some score exceeds it by more than RESCALE_THR
         // (always on the first step). Everything at the old reference - O, the denominator - is rescaled exactly once.
         float lmax[QT];
-        bool need = k0 == 0;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            lmax[t] = fmaxf(fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3])),
-                            fmaxf(fmaxf(s[t][1][0], s[t][1][1]), fmaxf(s[t][1][2], s[t][1][3])));
-            need = need || lmax[t] > RESCALE_THR;
+            lmax[t] = max3(s[t][0][0], s[t][0][1], s[t][0][2]);
+            lmax[t] = max3(lmax[t], s[t][0][3], s[t][1][0]);
+            lmax[t] = max3(lmax[t], s[t][1][1], s[t][1][2]);
+            lmax[t] = max3(lmax[t], s[t][1][3], s[t][1][3]);
         }
+        float lall = lmax[0];
+#pragma unroll
+        for (int t = 1; t + 1 < QT; t += 2) lall = max3(lall, lmax[t], lmax[t + 1]);
+        if (QT % 2 == 0) lall = max3(lall, lmax[QT - 1], lmax[QT - 1]);
+        const bool need = k0 == 0 || lall > RESCALE_THR;
         if (__any(need)) {
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 float mx = xor32_max(xor16_max(lmax[t]));           // row max relative to the current reference
                 mx = k0 == 0 ? mx : fmaxf(mx, 0.f);                 // the reference never decreases after step 0
                 const float alpha = __builtin_amdgcn_exp2f(-mx);
-                m_run[t] += mx;
+                negm[t] -= mx;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) s[t][kt] -= mx;
                 lsum[t] *= alpha;

@@ -164,7 +164,7 @@ class ForwardPlan:
         self.images = None           # allocated only if the caller's tensor cannot be read in place
         self.x = z(rows, C)
         xn, att = z(rows, C), z(rows, C)
-        hid = None if K.mlp_fused_supported(C, self.T) else z(rows, 4 * C)
+        hid = None if K.mlp_fused_supported(C, self.T, rows) else z(rows, 4 * C)
         q, k, vt = z(B, heads, Tp, hd), z(B, heads, Tp, hd), z(B, heads, hd, Tp)
         ntap = len(self.taps)
         self.taps_cat = z(rows, ntap * C)
@@ -177,7 +177,7 @@ class ForwardPlan:
             a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
         self.patch_op = ops[-1]
         qscale = K.attention_scale(hd)
-        fused = K.mlp_fused_supported(C, self.T)
+        fused = K.mlp_fused_supported(C, self.T, rows)
         for i in range(self.depth):
             blk = f"{pre}.blocks.{i}"
             window = i in self.cfg.window_block_indexes

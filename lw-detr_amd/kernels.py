@@ -3,6 +3,8 @@ replayed with one ctypes call per launch, so a forward pass is a flat list of pr
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from . import _native as _nat
@@ -118,9 +120,23 @@ class LayerNormOp:
             _nat.check(rc, "layernorm")
 
 
-def mlp_fused_supported(C_, dtype) -> bool:
-    """Shapes the fused MLP kernel is instantiated for (LDS / register budget): C=192 any dtype, C=384 16-bit."""
-    return C_ == 192 or (C_ == 384 and dtype in (torch.float16, torch.bfloat16))
+MLP_FUSED_MIN_ROWS = 12800      # below ~8 images of 640x640 the per-tile latency of the fused kernel loses to small GEMMs
+
+
+def mlp_fused_supported(C_, dtype, rows=None) -> bool:
+    """Shapes the fused MLP kernel is instantiated for (LDS / register budget): C=192 any dtype, C=384 16-bit.
+
+    With ``rows`` given this is the launch-plan choice: the fused kernel gives every wave ONE 32-token tile and walks all
+    hidden chunks with it, so its run time is flat (~70-100 us) up to 65k tokens; for a few images the 6 separate launches
+    (LN, QKV, proj, LN, fc1+GELU, fc2) spread the same work over all CUs and win (bs=1 latency). LWDETR_MLP_FUSED=0/1
+    forces either."""
+    ok = C_ == 192 or (C_ == 384 and dtype in (torch.float16, torch.bfloat16))
+    if not ok or rows is None:
+        return ok
+    force = os.environ.get("LWDETR_MLP_FUSED")
+    if force in ("0", "1"):
+        return force == "1"
+    return rows >= MLP_FUSED_MIN_ROWS
 
 
 _KSLOT_PERM = [4 * g_ + e + 16 * hi for g_ in range(4) for hi in range(2) for e in range(4)]

@@ -31,8 +31,16 @@ def _diffs(out, g):
     return {k: float(v) for k, v in d.items()}
 
 
+@pytest.fixture(params=["1", "0"], ids=["mlp-fused", "mlp-unfused"])
+def mlp_path(request, monkeypatch):
+    """Both launch plans of the ViT blocks: the fused MLP mega-kernel (picked by itself for >= 8 images) and the separate
+    LN / GEMM launches (picked for small batches); the golden batches are 1-2 images, so force each in turn."""
+    monkeypatch.setenv("LWDETR_MLP_FUSED", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", list(CASES))
-def test_fp32_matches_reference_golden(name):
+def test_fp32_matches_reference_golden(name, mlp_path):
     """fp32 HIP path vs the unmodified reference's CPU outputs (north star: every box / logit tensor within 1e-3).
 
     The two-stage top-k is order sensitive: memory rows of padded / invalid cells are bit-identical (exact score ties)
@@ -55,7 +63,7 @@ def test_fp32_matches_reference_golden(name):
         out = model(nt, _forced_topk=torch.from_numpy(ref_idx).to(DEV))
     d = _diffs(out, g)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"parity_fp32_{name}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_fp32_{name}_mlp{mlp_path}.json"), "w") as f:
         json.dump({"diffs": d, "topk_same_slots": same_slots, "topk_ref_score_gap": gap}, f)
     assert max(d.values()) < FP32_TOL, d
     # PostProcess on the HIP outputs reproduces the reference's detections
@@ -92,7 +100,7 @@ def test_fp32_stages_match_oracle(name):
 @pytest.mark.parametrize("name,dtype,tol_mem,tol_out", [("small_640", torch.float16, 0.05, 0.15),
                                                          ("medium_640", torch.bfloat16, 0.3, 0.8),
                                                          ("xlarge_960", torch.float16, 0.08, 0.25)])
-def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_out):
+def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_out, mlp_path):
     """fp16 / bf16 compute (BASELINE configs 2, 3, 5): compared with teacher-forced two-stage indices - slot-wise
     comparison under a free top-k is meaningless at these precisions; the selected SET is checked."""
     g = load_golden(name)
