@@ -109,7 +109,7 @@ typedef struct {
     int B, heads, hd, Tp;
     int seqs_per_img;   /* 16 (window attention) or 1 */
     int seq_tok_stride; /* tokens between consecutive sequences of one image */
-    int keys_per_seq;   /* tokens (incl. pad rows) spanned by one sequence */
+    int keys_per_seq;   /* tokens (incl. pad rows) spanned by one sequence; >= 8 and a multiple of 4 */
     int sub_stride, sub_len; /* key j is real iff (j % sub_stride) < sub_len */
     int kind;           /* 0 window, 1 global, 2 decoder self-attention (profiling label only) */
 } lwdetr_attn_desc;

@@ -45,6 +45,12 @@ __device__ __forceinline__ float xor32_sum(float v) {
 // softmax instruction count is kernel time. Infinities stay honoured (the key mask is -inf).
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
+// Tuning builds (tools/attn_ablate.py, -DLWDETR_ATTN_ABL=n, wrong results): 1 = no exp2, 2 = no row max / rescale check,
+// 4 = no score MFMAs, 8 = no P V / row-sum MFMAs, 16 = no float -> T conversion of P. Bits combine.
+#ifndef LWDETR_ATTN_ABL
+#define LWDETR_ATTN_ABL 0
+#endif
+
 template <typename T, int HD, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     typedef typename Vec<T>::v8 V8;
@@ -100,10 +106,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     // K / V^T operand fragments of one 32-key step; loaded one step ahead (software pipelining: the loads of step i+1
     // are in flight while step i runs its MFMAs and exps)
     struct KV { V8 k8[2][NC]; V4 k4[2]; V8 v[DT]; };
+    // Key order inside a 32-key step: score tile kt, row 4g + r  <->  key k0 + 8g + 4kt + r. Any row order is as good as
+    // another for S^T = K Q^T, and with this one the 8 k-slots a lane owns in O^T = V^T P^T (slots 0-3 from tile 0, 4-7 from
+    // tile 1, rows 4g..4g+3 of each) are the 8 CONSECUTIVE keys k0 + 8g .. + 7: one 16-byte V^T load per lane and step.
     auto load_kv = [&](int k0, KV& f) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            int key = k0 + kt * 16 + l15; key = key < last ? key : last;
+            int key = k0 + 8 * (l15 >> 2) + 4 * kt + (l15 & 3); key = key < last ? key : last;
             if (HD >= 32) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) f.k8[kt][c] = *(const V8*)(Kb + (long)key * HD + c * 32 + g * 8);
@@ -111,27 +120,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
                 f.k4[kt] = *(const V4*)(Kb + (long)key * HD + g * 4);
             }
         }
-        // V^T (A operand of O^T = V^T P^T): k-slots 0..3 <- keys k0+4g.., slots 4..7 <- keys k0+16+4g..
-        int ka = k0 + g * 4, kb = k0 + 16 + g * 4;
-        ka = ka + 3 < nkeys ? ka : (nkeys - 4);
-        kb = kb + 3 < nkeys ? kb : (nkeys - 4);
+        int kv = k0 + g * 8;
+        kv = kv + 7 < nkeys ? kv : (nkeys - 8);                      // whole run in range or clamped (masked below)
+        // clamped only in a ragged last step; keys_per_seq is a multiple of 4, so the run then starts 4 (mod 8) keys early
+        // (or >= 8 early: every slot is a key past the end and P = 0 there)
+        const bool shift4 = k0 + g * 8 - kv == 4;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const T* vrow = Vb + (long)(dt * 16 + l15) * p.Tp;
-            const V4 lo = *(const V4*)(vrow + ka), hi = *(const V4*)(vrow + kb);
+            V8 v = *(const V8*)(Vb + (long)(dt * 16 + l15) * p.Tp + kv);
+            if (shift4) {                                            // keep slot e <-> key k0 + 8g + e for the 4 valid keys
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { f.v[dt][e] = lo[e]; f.v[dt][4 + e] = hi[e]; }
+                for (int e = 0; e < 4; ++e) v[e] = v[4 + e];
+            }
+            f.v[dt] = v;
         }
     };
 
     auto step = [&](const KV& f, int k0) {
-        // ---- S'^T tiles: s[t][kt][r] = score(key k0 + kt*16 + 4g + r, query q0 + t*16 + l15) - m_run[t]
+        // ---- S'^T tiles: s[t][kt][r] = score(key k0 + 8g + 4kt + r, query q0 + t*16 + l15) - m_run[t]
         f32x4 s[QT][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 f32x4 a = negm[t];
+                if (LWDETR_ATTN_ABL & 4) { a[0] += to_f32<T>(f.k4[kt][0]); s[t][kt] = a; continue; }
                 if (HD >= 32) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) a = Mma<T>::k32(f.k8[kt][c], q8[t][c], a);
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kt * 16 + g * 4 + r;
+                    const int key = k0 + g * 8 + kt * 4 + r;
                     const int sub = holes ? key % p.sub_stride : 0;
                     const bool ok = (key < nkeys) & (sub < p.sub_len);
 #pragma unroll
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
             lmax[t] = max3(lmax[t], s[t][1][1], s[t][1][2]);
             lmax[t] = max3(lmax[t], s[t][1][3], s[t][1][3]);
         }
+        if (LWDETR_ATTN_ABL & 2) { for (int t = 0; t < QT; ++t) lmax[t] = s[t][0][0]; }
         float lall = lmax[0];
 #pragma unroll
         for (int t = 1; t + 1 < QT; t += 2) lall = max3(lall, lmax[t], lmax[t + 1]);
@@ -190,24 +204,47 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pf[kt * 4 + r] = from_f32<T>(__builtin_amdgcn_exp2f(s[t][kt][r]));
+                for (int r = 0; r < 4; ++r) {
+                    const float e = (LWDETR_ATTN_ABL & 1) ? s[t][kt][r] : __builtin_amdgcn_exp2f(s[t][kt][r]);
+                    pf[kt * 4 + r] = from_f32<T>(e);
+                }
+            if (LWDETR_ATTN_ABL & 8) { lsum[t][0] += to_f32<T>(pf[0]) + to_f32<T>(pf[5]); continue; }
             lsum[t] = Mma<T>::k32(ones, pf, lsum[t]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) o[t][dt] = Mma<T>::k32(f.v[dt], pf, o[t][dt]);
         }
     };
 
+    // The loads of step i + 1 are issued UNCONDITIONALLY (addresses are clamped, a step past the end fetches rows that are
+    // never used): with the issue under an `if`, hipcc merges the "nothing new in flight" path into the waits and drains
+    // the queue (s_waitcnt vmcnt(0)) right before the MFMAs that need step i's operands - i.e. it waits for the loads it
+    // has just issued, one exposed L2 round trip per step.
+    // (Short sequences - a 100-key window is 4 steps - keep the conditional form: one wasted fetch per wave costs more
+    // there than the drained queue.)
     KV fa, fb;
     load_kv(0, fa);
-    for (int k0 = 0;;) {
-        if (k0 + 32 < nkeys) load_kv(k0 + 32, fb);
-        step(fa, k0);
-        k0 += 32;
-        if (k0 >= nkeys) break;
-        if (k0 + 32 < nkeys) load_kv(k0 + 32, fa);
-        step(fb, k0);
-        k0 += 32;
-        if (k0 >= nkeys) break;
+    if (nkeys >= 512) {
+        for (int k0 = 0;;) {
+            load_kv(k0 + 32, fb);
+            step(fa, k0);
+            k0 += 32;
+            if (k0 >= nkeys) break;
+            load_kv(k0 + 32, fa);
+            step(fb, k0);
+            k0 += 32;
+            if (k0 >= nkeys) break;
+        }
+    } else {
+        for (int k0 = 0;;) {
+            if (k0 + 32 < nkeys) load_kv(k0 + 32, fb);
+            step(fa, k0);
+            k0 += 32;
+            if (k0 >= nkeys) break;
+            if (k0 + 32 < nkeys) load_kv(k0 + 32, fa);
+            step(fb, k0);
+            k0 += 32;
+            if (k0 >= nkeys) break;
+        }
     }
 
     // ---- normalise and store: lane holds channels dt*16 + 4g .. +3 of query q0 + t*16 + l15
@@ -269,7 +306,7 @@ extern "C" int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* h
     if (!desc) return LWDETR_ERR_BAD_ARG;
     const lwdetr_attn_desc& p = *desc;
     if (!p.Q || !p.K || !p.VT || !p.out || p.B <= 0 || p.heads <= 0 || p.Tp <= 0 || p.Tp % 4 != 0) return LWDETR_ERR_BAD_ARG;
-    if (p.seqs_per_img <= 0 || p.keys_per_seq < 4 || p.keys_per_seq % 4 != 0 || p.sub_stride <= 0 || p.sub_len <= 0 || p.sub_len > p.sub_stride)
+    if (p.seqs_per_img <= 0 || p.keys_per_seq < 8 || p.keys_per_seq % 4 != 0 || p.sub_stride <= 0 || p.sub_len <= 0 || p.sub_len > p.sub_stride)
         return LWDETR_ERR_BAD_ARG;
     if ((long)(p.seqs_per_img - 1) * p.seq_tok_stride + p.keys_per_seq > p.Tp) return LWDETR_ERR_BAD_ARG;
     if (p.seq_tok_stride % 4 != 0 || p.ldo % 4 != 0) return LWDETR_ERR_BAD_ARG;

@@ -44,6 +44,45 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) cyc[wave] = t1 - t0;
 }
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int KIND>
+__global__ __launch_bounds__(256) void kmf(float* out, unsigned long long* cyc, int iters) {
+    f16x8 a8, b8; f16x4 a4, b4;
+    for (int i = 0; i < 8; ++i) { a8[i] = (_Float16)(threadIdx.x * 0.001f + i); b8[i] = (_Float16)(i * 0.5f); }
+    for (int i = 0; i < 4; ++i) { a4[i] = a8[i]; b4[i] = b8[i]; }
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16 acc32[2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (KIND == 0) acc[r] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[r], 0, 0, 0);
+            if (KIND == 1) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[r], 0, 0, 0);
+            if (KIND == 2) acc32[r & 1] = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, b4, acc32[r & 1], 0, 0, 0);
+            if (KIND == 3) acc32[r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc32[r & 1], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 16; ++j) s += acc32[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int KIND> void runk(const char* what) {
+    float* out; unsigned long long* cyc; unsigned long long h[8] = {0};
+    hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 64);
+    const int iters = 200;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((kmf<KIND>), dim3(256), dim3(256), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+    printf("%-30s %.1f cycles per MFMA (1 wave/SIMD)\n", what, (double)h[0] / (iters * 8.0));
+    hipFree(out); hipFree(cyc);
+}
+
 template <int NMFMA, int NVALU, int NTRANS, int NLDS>
 __global__ __launch_bounds__(512) void k32(float* out, unsigned long long* cyc, int iters) {
     __shared__ float4 lds[1024];
@@ -108,6 +147,7 @@ void run(int threads, const char* what) {
 }
 
 int main() {
+    runk<0>("16x16x16 f16 (legacy)"); runk<1>("16x16x32 f16"); runk<2>("32x32x8 f16 (legacy)"); runk<3>("32x32x16 f16");
     run<1, 0, 0, false>(256, "1 mfma16");
     run<1, 4, 0, false>(256, "1 mfma16 + 4 fma");
     run32<1, 0, 0, 0>(256, "1 mfma32x32x16");
