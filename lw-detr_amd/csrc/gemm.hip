@@ -500,7 +500,18 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     long tiles_m = (d.M + 127) / 128, tiles_n = (d.N + BNsel - 1) / BNsel;
     // small problems (decoder / head GEMMs: a few thousand rows) would leave most of the 256 CUs idle with 128-row
     // tiles: switch to 64 x 64 tiles when the 128-row grid has fewer than ~1.5 workgroups per CU
-    const bool small = tiles_m * tiles_n < 384;
+    // Measured per shape on MI355X (tools/op_times.py with LWDETR_GEMM_TILE=1|2|3, B=32 small model): 64 x 64 tiles win
+    // or tie on every plain / patch GEMM of the network (K <= 2048, N <= 2048: short k-loops, the tile's prologue and
+    // epilogue latency is what more, smaller workgroups hide); only the implicit-GEMM 3x3 convolutions (K = 9 Cin, a
+    // gathered A panel worth re-using across 128 columns) are faster with 128 x 128.
+    bool small = AMODE != LWDETR_A_CONV3x3 || tiles_m * tiles_n < 384;
+    static const char* tile_env = getenv("LWDETR_GEMM_TILE");      // tuning: 1 = 64x64, 2 = 128x64, 3 = 128x128 (where legal)
+    if (tile_env) {
+        const int tsel = atoi(tile_env);
+        if (tsel == 1) small = true;
+        if (tsel == 2) { small = false; bn64 = true; tiles_n = (d.N + 63) / 64; }
+        if (tsel == 3 && !bn64) small = false;
+    }
     if (small) { tiles_m = (d.M + 63) / 64; tiles_n = (d.N + 63) / 64; }
     const long nwg = tiles_m * tiles_n;
     if (nwg <= 0 || nwg > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
