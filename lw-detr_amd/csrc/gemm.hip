@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
         w_src[k] = n < d.N ? W + (long)n * d.K + ccol : nullptr;
     }
     const int nk = d.K / BK;
+    const T* conv_src[A_MY]; int conv_tap[A_MY];
+#pragma unroll
+    for (int k = 0; k < A_MY; ++k) { conv_src[k] = nullptr; conv_tap[k] = -1; }
     auto stage = [&](int kt) {           // always PER_TILE pieces; tiles past the end of K read the zero page
         T* As = smem + (kt % NST) * STAGE;
         T* Bs = As + BM * BK;
@@ -425,11 +428,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
             if (AMODE == LWDETR_A_PLAIN) {
                 if (live && a_src[k]) src = a_src[k] + k0;
             } else if (AMODE == LWDETR_A_CONV3x3) {
+                // the shifted source row only changes with the tap (every Cin / 32 stages): its address (bounds test,
+                // token encode: ~40 VALU instructions per piece) is kept across the stages of a tap
                 const int tap = k0 / d.conv_cin;                    // uniform: Cin % 32 == 0
-                const int ci = k0 - tap * d.conv_cin + ccol;
-                const int iy = a_y[k] * d.conv_stride + tap / 3 - 1, ix = a_x[k] * d.conv_stride + tap % 3 - 1;
-                if (live && a_b[k] >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp)
-                    src = A + tok_encode(a_b[k], iy, ix, d.a_tok) * d.lda + d.a_col0 + ci;
+                if (tap != conv_tap[k]) {
+                    conv_tap[k] = tap;
+                    const int iy = a_y[k] * d.conv_stride + tap / 3 - 1, ix = a_x[k] * d.conv_stride + tap % 3 - 1;
+                    conv_src[k] = (a_b[k] >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp)
+                                      ? A + tok_encode(a_b[k], iy, ix, d.a_tok) * d.lda + d.a_col0 + ccol : nullptr;
+                }
+                if (live && conv_src[k]) src = conv_src[k] + (k0 - tap * d.conv_cin);
             } else {
                 const int kk = k0 + ccol, ch = kk >> 8, py = (kk >> 4) & 15, px = kk & 15;
                 if (live && a_b[k] >= 0)

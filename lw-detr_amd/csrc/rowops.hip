@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void decoder_inputs_kernel(const T* __restrict
     for (int c = threadIdx.x; c < 2 * d; c += blockDim.x) {
         const int k = c / half, i = c - k * half;
         const float e = pos[k] * 6.283185307179586f / dim_t[i];
-        sine[row * 2 * d + c] = from_f32<T>((i & 1) ? cosf(e) : sinf(e));
+        sine[row * 2 * d + c] = from_f32<T>((i & 1) ? __cosf(e) : __sinf(e));   // |e| <= a few 2 pi: v_sin/v_cos, ~1e-6 abs
     }
     for (int c = threadIdx.x; c < d; c += blockDim.x) xdec[row * d + c] = query_feat[(long)q * d + c];
 }
