@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     // Key order inside a 32-key step: score tile kt, row 4g + r  <->  key k0 + 8g + 4kt + r. Any row order is as good as
     // another for S^T = K Q^T, and with this one the 8 k-slots a lane owns in O^T = V^T P^T (slots 0-3 from tile 0, 4-7 from
     // tile 1, rows 4g..4g+3 of each) are the 8 CONSECUTIVE keys k0 + 8g .. + 7: one 16-byte V^T load per lane and step.
-    auto load_kv = [&](int k0, KV& f) {
+    auto load_k = [&](int k0, KV& f) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             int key = k0 + 8 * (l15 >> 2) + 4 * kt + (l15 & 3); key = key < last ? key : last;
@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
                 f.k4[kt] = *(const V4*)(Kb + (long)key * HD + g * 4);
             }
         }
+    };
+    auto load_v = [&](int k0, KV& f) {
         int kv = k0 + g * 8;
         kv = kv + 7 < nkeys ? kv : (nkeys - 8);                      // whole run in range or clamped (masked below)
         // clamped only in a ragged last step; keys_per_seq is a multiple of 4, so the run then starts 4 (mod 8) keys early
@@ -135,27 +137,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
             f.v[dt] = v;
         }
     };
+    auto load_kv = [&](int k0, KV& f) { load_k(k0, f); load_v(k0, f); };
 
-    auto step = [&](const KV& f, int k0) {
-        // ---- S'^T tiles: s[t][kt][r] = score(key k0 + 8g + 4kt + r, query q0 + t*16 + l15) - m_run[t]
-        f32x4 s[QT][2];
+    // score tiles of one query tile against the two key tiles of a step (C operand = -reference)
+    auto qk_tile = [&](const KV& f, int t, f32x4 (&st)[2]) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+            f32x4 a = negm[t];
+            if (LWDETR_ATTN_ABL & 4) { a[0] += to_f32<T>(f.k4[kt][0]); st[kt] = a; continue; }
+            if (HD >= 32) {
 #pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                f32x4 a = negm[t];
-                if (LWDETR_ATTN_ABL & 4) { a[0] += to_f32<T>(f.k4[kt][0]); s[t][kt] = a; continue; }
-                if (HD >= 32) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) a = Mma<T>::k32(f.k8[kt][c], q8[t][c], a);
-                } else {
-                    a = Mma<T>::k16(f.k4[kt], q4[t], a);
-                }
-                s[t][kt] = a;
+                for (int c = 0; c < NC; ++c) a = Mma<T>::k32(f.k8[kt][c], q8[t][c], a);
+            } else {
+                a = Mma<T>::k16(f.k4[kt], q4[t], a);
             }
+            st[kt] = a;
         }
-        // ---- mask keys beyond the sequence / pad rows inside it (plain selects: a nested-branch formulation of this
-        // block was miscompiled by hipcc 7.2 - the inner condition's select got dropped)
+    };
+    // mask keys beyond the sequence / pad rows inside it, row maxima, lazy rescale (the reference only moves when some
+    // score exceeds it by more than RESCALE_THR - always on the first step; O and the denominator follow exactly once)
+    auto softmax_head = [&](f32x4 (&s)[QT][2], int k0) {
+        // plain selects: a nested-branch formulation of this block was miscompiled by hipcc 7.2 (inner select dropped)
         if (k0 + 32 > nkeys || holes) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -168,8 +170,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
                     for (int t = 0; t < QT; ++t) s[t][kt][r] = ok ? s[t][kt][r] : -INFINITY;
                 }
         }
-        // ---- lazy online softmax: the reference only moves when some score exceeds it by more than RESCALE_THR
-        // (always on the first step). Everything at the old reference - O, the denominator - is rescaled exactly once.
         float lmax[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -198,22 +198,33 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
                 for (int dt = 0; dt < DT; ++dt) o[t][dt] *= alpha;
             }
         }
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            V8 pf;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = (LWDETR_ATTN_ABL & 1) ? s[t][kt][r] : __builtin_amdgcn_exp2f(s[t][kt][r]);
-                    pf[kt * 4 + r] = from_f32<T>(e);
-                }
-            if (LWDETR_ATTN_ABL & 8) { lsum[t][0] += to_f32<T>(pf[0]) + to_f32<T>(pf[5]); continue; }
-            lsum[t] = Mma<T>::k32(ones, pf, lsum[t]);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) o[t][dt] = Mma<T>::k32(f.v[dt], pf, o[t][dt]);
-        }
     };
+    // P = 2^s of one query tile (already the B operand), row sum and O^T accumulation
+    auto pv_tile = [&](const KV& f, int t, const f32x4 (&st)[2]) {
+        V8 pf;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (LWDETR_ATTN_ABL & 1) ? st[kt][r] : __builtin_amdgcn_exp2f(st[kt][r]);
+                pf[kt * 4 + r] = from_f32<T>(e);
+            }
+        if (LWDETR_ATTN_ABL & 8) { lsum[t][0] += to_f32<T>(pf[0]) + to_f32<T>(pf[5]); return; }
+        lsum[t] = Mma<T>::k32(ones, pf, lsum[t]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[t][dt] = Mma<T>::k32(f.v[dt], pf, o[t][dt]);
+    };
+    auto step = [&](const KV& f, int k0) {
+        f32x4 s[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) qk_tile(f, t, s[t]);
+        softmax_head(s, k0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) pv_tile(f, t, s[t]);
+    };
+    // (Tried and measured slower, 185 -> 192 us on the 1600-key shape: issuing the score MFMAs of step i + 1 tile by tile
+    // between the exponentials of step i. Transcendentals, MFMAs and plain VALU of the waves of a SIMD add up on this chip
+    // whatever the interleaving; only the instruction count moves the time.)
 
     // The loads of step i + 1 are issued UNCONDITIONALLY (addresses are clamped, a step past the end fetches rows that are
     // never used): with the issue under an `if`, hipcc merges the "nothing new in flight" path into the waits and drains
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     // (Short sequences - a 100-key window is 4 steps - keep the conditional form: one wasted fetch per wave costs more
     // there than the drained queue.)
     KV fa, fb;
-    load_kv(0, fa);
     if (nkeys >= 512) {
+        load_kv(0, fa);
         for (int k0 = 0;;) {
             load_kv(k0 + 32, fb);
             step(fa, k0);
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
             if (k0 >= nkeys) break;
         }
     } else {
+        load_kv(0, fa);
         for (int k0 = 0;;) {
             if (k0 + 32 < nkeys) load_kv(k0 + 32, fb);
             step(fa, k0);
