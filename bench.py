@@ -168,7 +168,7 @@ def main():
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4)}
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r1c_hbm_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")           # tools/profile_round.sh, this workload
         if os.path.exists(tf) and (a.size, a.batch, a.res, a.dtype) == ("small", 32, 640, "fp16"):
             traffic = json.load(open(tf)).get(name, {}).get("bytes_per_launch")      # rocprofv3 PMC pass of this workload
         roof.update({"kernel": name, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": v["count"],
