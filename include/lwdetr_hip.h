@@ -168,6 +168,24 @@ int lwdetr_topk(const void* x, int B, int N, int K, int64_t* idx_out, float* val
 int lwdetr_postprocess(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
                        float* scores, int64_t* labels, float* out_boxes, int dtype, void* hip_stream);
 
+/* ---- input side: uint8 HWC -> Pillow-exact bilinear square resize -> ToTensor -> Normalize -> NCHW --
+ * Replaces datasets/transforms.py:223-231 (SquareResize = PIL.Image.resize((S,S), BILINEAR)), :437-443 (Normalize) and
+ * ToTensor (datasets/coco.py:127-130, deploy/benchmark.py:273-281). One descriptor per image (a DEVICE array):
+ * src = uint8 RGB rows of `width` pixels, `row_stride` bytes apart; the *_off fields index `tables` (int32, device):
+ * bounds = (first input index, tap count) per output column / row, coef = `ksize` 22-bit fixed-point taps per output
+ * column / row (Pillow's precompute_coeffs + normalize_coeffs_8bpc, computed by the host); tmp_off = byte offset of this
+ * image's height x S x 3 intermediate in `tmp`. lut = 3 x 256 floats, (v / 255 - mean[c]) / std[c]. out = (B,3,S,S). */
+typedef struct {
+    const uint8_t* src;
+    int height, width;
+    long row_stride;
+    int xbounds_off, xcoef_off, xksize;
+    int ybounds_off, ycoef_off, yksize;
+    long tmp_off;
+} lwdetr_resize_image;
+int lwdetr_resize_normalize(const lwdetr_resize_image* images, int B, int max_height, const int32_t* tables, uint8_t* tmp,
+                            const float* lut, void* out, int S, int dtype, void* hip_stream);
+
 /* ---- profiling: per-kernel HIP-event timing on the launch stream (off by default) ------------------------------ */
 int lwdetr_prof_enable(int on);
 int lwdetr_prof_num_kernels(void);

@@ -34,14 +34,15 @@ def test_ctypes_structs_match_header_layout(built):
     """sizeof() of the ctypes mirrors equals what a C compiler computes for the header's structs."""
     import subprocess
     import tempfile
-    src = '#include <stdio.h>\n#include "lwdetr_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(lwdetr_tok_layout),' \
-          ' sizeof(lwdetr_gemm_seg), sizeof(lwdetr_gemm_desc), sizeof(lwdetr_attn_desc));return 0;}\n'
+    src = '#include <stdio.h>\n#include "lwdetr_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(lwdetr_tok_layout),' \
+          ' sizeof(lwdetr_gemm_seg), sizeof(lwdetr_gemm_desc), sizeof(lwdetr_attn_desc), sizeof(lwdetr_resize_image));return 0;}\n'
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "s.c"), "-o", os.path.join(td, "s")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "s")]).split()]
+    from lwdetr_amd.preprocess import ResizeImage
     assert sizes == [ctypes.sizeof(built.TokLayout), ctypes.sizeof(built.GemmSeg), ctypes.sizeof(built.GemmDesc),
-                     ctypes.sizeof(built.AttnDesc)]
+                     ctypes.sizeof(built.AttnDesc), ctypes.sizeof(ResizeImage)]
 
 
 def test_prof_api_without_gpu(built):
