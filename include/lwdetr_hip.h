@@ -13,6 +13,8 @@
  *   lwdetr_msda_forward        models/ops/src/ms_deform_attn.h:19-35 (ms_deform_attn_forward, pybind
  *                              models/ops/src/vision.cpp:13-16) -> cuda/ms_deform_attn_cuda.cu:20-80 ->
  *                              cuda/ms_deform_im2col_cuda.cuh:237-299
+ *   lwdetr_msda_backward       models/ops/src/ms_deform_attn.h:37-60 (ms_deform_attn_backward) ->
+ *                              cuda/ms_deform_attn_cuda.cu:83-153 -> cuda/ms_deform_im2col_cuda.cuh:87-160, :846-920
  *   lwdetr_msda_fused_forward  models/ops/modules/ms_deform_attn.py:117-142 (softmax, location arithmetic, op call)
  *   lwdetr_gemm                torch.nn.functional.linear / conv2d / conv_transpose2d call sites of
  *                              models/backbone/vit.py:79-83,:123-138, timm Mlp, models/backbone/projector.py:85-132,
@@ -42,6 +44,14 @@ extern "C" {
 int lwdetr_msda_forward(const void* value, const int64_t* shapes, const int64_t* level_start, const void* loc,
                         const void* attn, void* out, int B, int S, int M, int D, int L, int Q, int P, int dtype,
                         void* hip_stream);
+
+/* Backward of the op (reference ms_deform_attn_backward, models/ops/src/ms_deform_attn.h:37-60 ->
+ * cuda/ms_deform_attn_cuda.cu:83-153 -> cuda/ms_deform_im2col_cuda.cuh:87-160, :846-920): grad_out (B,Q,M*D) ->
+ * grad_value (B,S,M,D) (zeroed here, then accumulated with atomics), grad_loc (B,Q,M,L,P,2), grad_attn (B,Q,M,L,P),
+ * all fully written. dtype 0 (float32) or 3 (float64), as in the reference. */
+int lwdetr_msda_backward(const void* value, const int64_t* shapes, const int64_t* level_start, const void* loc,
+                         const void* attn, const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn,
+                         int B, int S, int M, int D, int L, int Q, int P, int dtype, void* hip_stream);
 
 /* Model-path variant: oa is the (B*Q, ld_oa) output of the fused sampling_offsets|attention_weights Linear
  * (offsets at column 0: M*L*P*2 values, logits at column logit_col: M*L*P values); ref_boxes (B,Q,4) f32 (cx,cy,w,h);

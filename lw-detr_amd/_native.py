@@ -68,6 +68,7 @@ def lib():
         l = C.CDLL(LIB_PATH)
         vp, i, lg, f = C.c_void_p, C.c_int, C.c_long, C.c_float
         l.lwdetr_msda_forward.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
+        l.lwdetr_msda_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
         l.lwdetr_msda_fused_forward.argtypes = [vp, vp, vp, vp, lg, i, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
         l.lwdetr_gemm.argtypes = [C.POINTER(GemmDesc), i, vp]
         l.lwdetr_attention.argtypes = [C.POINTER(AttnDesc), i, vp]
@@ -86,7 +87,7 @@ def lib():
         l.lwdetr_prof_kernel_name.argtypes = [i]
         l.lwdetr_prof_kernel_name.restype = C.c_char_p
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
-        for fn in ("lwdetr_msda_forward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
+        for fn in ("lwdetr_msda_forward", "lwdetr_msda_backward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
                    "lwdetr_layernorm", "lwdetr_mlp_fused", "lwdetr_select_gather", "lwdetr_decoder_inputs",
                    "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_resize_normalize", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int

@@ -256,6 +256,76 @@ template <typename T> int launch_fused(MsdaParams p, hipStream_t st) {
     return lwdetr_check_launch();
 }
 
+// --------------------------------------------------------------------------------------------- backward
+// col2im (reference ms_deform_im2col_cuda.cuh:87-160 corner gradients, :846-920 loop and in-range test; host contract
+// ms_deform_attn_cuda.cu:83-153). A group of GS = min(64, pow2(D)) lanes owns one (b, q, head); lanes stride the channels,
+// so the four corner reads and the grad_value atomics of a sampling point are contiguous, the location / weight reads are
+// group-uniform, and the channel reduction of d/d(loc) and d/d(weight) - shared-memory trees plus a second pass in the
+// reference (:301-845 has seven block-size variants of it) - is log2(GS) wave shuffles. grad_value uses hardware
+// floating-point atomics (unsafeAtomicAdd); like the reference's atomicAdd its summation order is not deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void msda_backward_kernel(MsdaParams p, const T* __restrict__ grad_out, T* __restrict__ grad_value,
+                                                            T* __restrict__ grad_loc, T* __restrict__ grad_aw, int GS) {
+    const int lane = threadIdx.x & 63, gl = lane & (GS - 1);
+    const int groups_per_block = 256 / GS;
+    const long item = (long)blockIdx.x * groups_per_block + (threadIdx.x / GS);      // (b, q, m)
+    const long nitems = (long)p.B * p.Q * p.M;
+    const bool live = item < nitems;
+    const long it = live ? item : nitems - 1;                                          // dead groups shadow the last item
+    const T* value = (const T*)p.value; const T* loc = (const T*)p.loc; const T* aw = (const T*)p.aw;
+    const int m = (int)(it % p.M);
+    const int b = (int)(it / ((long)p.M * p.Q));
+    const long ws = (long)p.M * p.D;
+    long wp = it * p.L * p.P;
+    for (int l = 0; l < p.L; ++l) {
+        const int H = (int)p.shapes[2 * l], W = (int)p.shapes[2 * l + 1];
+        const long voff = ((long)b * p.S + p.lsi[l]) * ws + (long)m * p.D;
+        for (int pt = 0; pt < p.P; ++pt, ++wp) {
+            const T w_im = loc[2 * wp] * W - (T)0.5, h_im = loc[2 * wp + 1] * H - (T)0.5;
+            const T a = aw[wp];
+            T ga = 0, gx = 0, gy = 0;
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+                const int hl = (int)floor(h_im), wl = (int)floor(w_im);
+                const T lh = h_im - hl, lw = w_im - wl, hh = 1 - lh, hw = 1 - lw;
+                const bool c1 = hl >= 0 && wl >= 0, c2 = hl >= 0 && wl + 1 <= W - 1;
+                const bool c3 = hl + 1 <= H - 1 && wl >= 0, c4 = hl + 1 <= H - 1 && wl + 1 <= W - 1;
+                const long o1 = voff + ((long)hl * W + wl) * ws, o2 = o1 + ws, o3 = o1 + (long)W * ws, o4 = o3 + ws;
+                for (int c = gl; c < p.D; c += GS) {
+                    const T tg = grad_out[it * p.D + c];
+                    const T tgv = tg * a;
+                    T v1 = 0, v2 = 0, v3 = 0, v4 = 0, gh = 0, gw = 0;
+                    if (c1) { v1 = value[o1 + c]; gh -= hw * v1; gw -= hh * v1; if (live) unsafeAtomicAdd(grad_value + o1 + c, hh * hw * tgv); }
+                    if (c2) { v2 = value[o2 + c]; gh -= lw * v2; gw += hh * v2; if (live) unsafeAtomicAdd(grad_value + o2 + c, hh * lw * tgv); }
+                    if (c3) { v3 = value[o3 + c]; gh += hw * v3; gw -= lh * v3; if (live) unsafeAtomicAdd(grad_value + o3 + c, lh * hw * tgv); }
+                    if (c4) { v4 = value[o4 + c]; gh += lw * v4; gw += lh * v4; if (live) unsafeAtomicAdd(grad_value + o4 + c, lh * lw * tgv); }
+                    ga += tg * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
+                    gx += (T)W * gw * tgv;
+                    gy += (T)H * gh * tgv;
+                }
+            }
+            for (int o = GS >> 1; o >= 1; o >>= 1) {
+                ga += __shfl_xor(ga, o); gx += __shfl_xor(gx, o); gy += __shfl_xor(gy, o);
+            }
+            if (live && gl == 0) { grad_aw[wp] = ga; grad_loc[2 * wp] = gx; grad_loc[2 * wp + 1] = gy; }
+        }
+    }
+}
+
+template <typename T> int launch_backward(MsdaParams p, const void* grad_out, void* grad_value, void* grad_loc, void* grad_aw,
+                                          hipStream_t st) {
+    if (hipMemsetAsync(grad_value, 0, (size_t)p.B * p.S * p.M * p.D * sizeof(T), st) != hipSuccess) return LWDETR_ERR_LAUNCH;
+    const long nitems = (long)p.B * p.Q * p.M;
+    if (nitems == 0) return LWDETR_OK;
+    int gs = 1;
+    while (gs < p.D && gs < 64) gs <<= 1;
+    const long per_block = 256 / gs, blocks = (nitems + per_block - 1) / per_block;
+    if (blocks > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
+    ProfScope ps(KID_MSDA_GENERIC, 0.0, 0.0, st);
+    hipLaunchKernelGGL((msda_backward_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, p, (const T*)grad_out, (T*)grad_value,
+                       (T*)grad_loc, (T*)grad_aw, gs);
+    return lwdetr_check_launch();
+}
+
 }  // namespace
 
 extern "C" {
@@ -278,6 +348,22 @@ int lwdetr_msda_forward(const void* value, const int64_t* shapes, const int64_t*
         case 3: return launch_plain<double>(p, st);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
+}
+
+int lwdetr_msda_backward(const void* value, const int64_t* shapes, const int64_t* level_start, const void* loc,
+                         const void* attn, const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn,
+                         int B, int S, int M, int D, int L, int Q, int P, int dtype, void* hip_stream) {
+    if (B < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Q < 0 || P <= 0) return LWDETR_ERR_BAD_ARG;
+    if (dtype != DT_F32 && dtype != 3) return LWDETR_ERR_UNSUPPORTED;          // the reference differentiates float / double only
+    if ((long)B * S * M * D == 0 && (long)B * Q * M == 0) return LWDETR_OK;
+    if (!value || !shapes || !level_start || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn)
+        return LWDETR_ERR_BAD_ARG;
+    MsdaParams p = {};
+    p.value = value; p.shapes = shapes; p.lsi = level_start; p.loc = loc; p.aw = attn;
+    p.B = B; p.S = S; p.M = M; p.D = D; p.L = L; p.Q = Q; p.P = P;
+    hipStream_t st = (hipStream_t)hip_stream;
+    return dtype == DT_F32 ? launch_backward<float>(p, grad_out, grad_value, grad_loc, grad_attn, st)
+                           : launch_backward<double>(p, grad_out, grad_value, grad_loc, grad_attn, st);
 }
 
 int lwdetr_msda_fused_forward(const void* value, const int64_t* shapes, const int64_t* level_start, const void* oa,

@@ -167,8 +167,46 @@ def run_op_kat():
     print("op KAT ->", path, "double out:", np.round(store["double_out"], 4).tolist())
 
 
+def run_op_grad_kat():
+    """Gradients of the reference's own differentiable CPU arithmetic for the op (``ms_deform_attn_core_pytorch`` through
+    autograd, double precision): the values ``ms_deform_attn_backward`` (ms_deform_attn_cuda.cu:83-153) must reproduce.
+    Shapes of models/ops/test.py:27-31 plus a model-like case with out-of-range locations and channel counts of the
+    reference's gradient checks (test.py:111: 30, 32, 64, 71)."""
+    import_reference()
+    from models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    store = {}
+    g = torch.Generator().manual_seed(11)
+    cases = {"kat": (1, 2, 2, 2, [(6, 4), (3, 2)], 2), "oob": (2, 4, 16, 37, [(20, 12), (10, 6)], 4),
+             "c30": (1, 2, 30, 5, [(6, 4), (3, 2)], 2), "c71": (1, 2, 71, 3, [(6, 4), (3, 2)], 2)}
+    for tag, (n, m, d, lq, sh, p) in cases.items():
+        shapes = torch.as_tensor(sh, dtype=torch.long)
+        l, s = len(sh), int((shapes[:, 0] * shapes[:, 1]).sum())
+        value = (torch.rand(n, s, m, d, generator=g, dtype=torch.float64) * 0.01 if tag == "kat"
+                 else torch.randn(n, s, m, d, generator=g, dtype=torch.float64)).requires_grad_(True)
+        loc = torch.rand(n, lq, m, l, p, 2, generator=g, dtype=torch.float64)
+        if tag == "oob":
+            loc = loc * 1.4 - 0.2
+        loc.requires_grad_(True)
+        aw = torch.rand(n, lq, m, l, p, generator=g, dtype=torch.float64) + 1e-5
+        aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).requires_grad_(True)
+        out = ms_deform_attn_core_pytorch(value.permute(0, 2, 3, 1).contiguous(), shapes, loc, aw)
+        go = torch.randn(out.shape, generator=g, dtype=torch.float64)
+        gv, gl, ga = torch.autograd.grad(out, (value, loc, aw), go)
+        for k, t in (("shapes", shapes), ("value", value), ("loc", loc), ("aw", aw), ("grad_out", go), ("grad_value", gv),
+                     ("grad_loc", gl), ("grad_aw", ga)):
+            store[f"{tag}_{k}"] = t.detach().numpy()
+    path = os.path.join(GOLDEN_DIR, "msda_op_grad_kat.npz")
+    np.savez_compressed(path, **store)
+    print("op gradient KAT ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     which = sys.argv[1:] or (["op_kat"] + list(CASES))
     for w in which:
-        run_op_kat() if w == "op_kat" else run_case(w)
+        if w == "op_kat":
+            run_op_kat()
+        elif w == "op_grad_kat":
+            run_op_grad_kat()
+        else:
+            run_case(w)

@@ -113,3 +113,68 @@ def test_fused_module_matches_oracle_module(dtype, tol, lp):
     mod = mod.to(DEV).to(dtype)
     out = mod(query.to(DEV, dtype), ref_in.to(DEV, dtype), memory.to(DEV, dtype), sh, _lsi(sh), mask.to(DEV))
     assert (out.float().cpu() - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------- backward
+@pytest.mark.parametrize("tag", ["kat", "oob", "c30", "c71"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_backward_matches_reference_autograd_goldens(tag, dtype):
+    """lwdetr_msda_backward vs autograd through the reference's PyTorch core (tests/golden/msda_op_grad_kat.npz) and vs the
+    C restatement of the reference's col2im kernel on the same inputs."""
+    from helpers import load_golden
+    from lwdetr_amd.ops.functions import ms_deform_attn_backward
+    from oracle import msda_c
+    g = load_golden("msda_op_grad_kat")
+    shapes = torch.from_numpy(g[f"{tag}_shapes"]).to(DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1])).contiguous()
+    value, loc, aw, go = (torch.from_numpy(g[f"{tag}_{k}"]).to(dtype).to(DEV).contiguous() for k in ("value", "loc", "aw", "grad_out"))
+    gv, gl, ga = ms_deform_attn_backward(value, shapes, lsi, loc, aw, go, 64)
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    for ours, key in ((gv, "grad_value"), (gl, "grad_loc"), (ga, "grad_aw")):
+        ref = g[f"{tag}_{key}"]
+        assert np.abs(ours.double().cpu().numpy() - ref).max() <= tol * max(1.0, float(np.abs(ref).max())), key
+    cv, cl, ca = msda_c.msda_backward(*(t.cpu().numpy() for t in (value,)), g[f"{tag}_shapes"],
+                                      *(t.cpu().numpy() for t in (loc, aw, go)))
+    ctol = 1e-12 if dtype == torch.float64 else 2e-5
+    assert np.abs(gv.cpu().numpy() - cv).max() <= ctol * max(1.0, float(np.abs(cv).max()))
+    assert np.abs(gl.cpu().numpy() - cl).max() <= ctol * 50 * max(1.0, float(np.abs(cl).max()))
+    assert np.abs(ga.cpu().numpy() - ca).max() <= ctol * 50 * max(1.0, float(np.abs(ca).max()))
+
+
+@pytest.mark.parametrize("channels", [30, 32, 64, 71])
+def test_function_gradcheck_double(channels):
+    """The reference's own gradient test (models/ops/test.py:89-112): numerical vs analytical gradients of
+    MSDeformAttnFunction in double precision, same shapes and channel counts."""
+    from lwdetr_amd.ops.functions import MSDeformAttnFunction
+    n, m, lq, l, p = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    s = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    value = (torch.rand(n, s, m, channels, device=DEV) * 0.01).double().requires_grad_(True)
+    loc = torch.rand(n, lq, m, l, p, 2, device=DEV).double().requires_grad_(True)
+    aw = torch.rand(n, lq, m, l, p, device=DEV) + 1e-5
+    aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2), nondet_tol=1e-12)
+
+
+def test_backward_model_shapes_and_module_autograd():
+    """Training-style use: gradients flow through the reference-compatible module into its parameters and inputs."""
+    from lwdetr_amd.ops.functions import MSDeformAttnFunction
+    b, q, m, d, p = 2, 300, 16, 16, 2
+    shapes = torch.as_tensor([(40, 40)], dtype=torch.long, device=DEV)
+    lsi = torch.zeros(1, dtype=torch.long, device=DEV)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    value = torch.randn(b, 1600, m, d, generator=g).to(DEV).requires_grad_(True)
+    loc = (torch.rand(b, q, m, 1, p, 2, generator=g) * 1.2 - 0.1).to(DEV).requires_grad_(True)
+    aw = torch.rand(b, q, m, 1, p, generator=g).softmax(-1).to(DEV).requires_grad_(True)
+    out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, aw, 64)
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    out.backward(go)
+    from oracle import lwdetr_torch as O
+    v2, l2, a2 = (t.detach().cpu().double().requires_grad_(True) for t in (value, loc, aw))
+    ref = O.msda_core(v2, [(40, 40)], l2, a2)
+    rv, rl, ra = torch.autograd.grad(ref, (v2, l2, a2), go.cpu().double())
+    assert (value.grad.cpu().double() - rv).abs().max().item() < 1e-4
+    assert (aw.grad.cpu().double() - ra).abs().max().item() < 1e-3
+    assert (loc.grad.cpu().double() - rl).abs().max().item() < 1e-3 * max(1.0, rl.abs().max().item())

@@ -44,3 +44,21 @@ def test_c_oracle_empty_and_ragged():
     aw = np.array([1.0, 1.0], np.float32).reshape(1, 1, 1, 1, 2)
     out = msda_c.msda_forward(value, shapes, loc, aw)
     np.testing.assert_allclose(out[0, 0], value[0, 1 * 5 + 2, 0], atol=1e-6)
+
+
+def test_c_oracle_backward_matches_reference_autograd():
+    """col2im restatement vs autograd through the reference's PyTorch core (tests/golden/msda_op_grad_kat.npz)."""
+    g = load_golden("msda_op_grad_kat")
+    for tag in ("kat", "oob", "c30", "c71"):
+        gv, gl, ga = msda_c.msda_backward(g[f"{tag}_value"], g[f"{tag}_shapes"], g[f"{tag}_loc"], g[f"{tag}_aw"],
+                                          g[f"{tag}_grad_out"])
+        np.testing.assert_allclose(gv, g[f"{tag}_grad_value"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(ga, g[f"{tag}_grad_aw"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gl, g[f"{tag}_grad_loc"], rtol=1e-8, atol=1e-11)
+        # float instantiation within float round-off of the double gradients
+        gv32, gl32, ga32 = msda_c.msda_backward(*(g[f"{tag}_{k}"].astype(np.float32) for k in ("value",)), g[f"{tag}_shapes"],
+                                                *(g[f"{tag}_{k}"].astype(np.float32) for k in ("loc", "aw", "grad_out")))
+        scale = max(1.0, float(np.abs(g[f"{tag}_grad_loc"]).max()))
+        assert np.abs(gv32 - g[f"{tag}_grad_value"]).max() < 1e-5
+        assert np.abs(ga32 - g[f"{tag}_grad_aw"]).max() < 1e-4 * max(1.0, float(np.abs(g[f"{tag}_grad_aw"]).max()))
+        assert np.abs(gl32 - g[f"{tag}_grad_loc"]).max() < 2e-4 * scale
