@@ -71,3 +71,54 @@ def detect_sharded(detect_fn, images, target_sizes):
     lo, hi = shard_range(total, rank, world)
     s, l, b = detect_fn(images[lo:hi], target_sizes[lo:hi])
     return unpack_detections(all_gather_detections(pack_detections(s, l, b)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The step after the path: hand the gathered detections to the COCO evaluator on rank 0 only.
+# The reference updates a CocoEvaluator on every rank and merges the per-rank pycocotools state through pickled
+# all_gathers (datasets/coco_eval.py:56-69, :181-200, engine.py:142-157); with the detections already gathered as one
+# fixed-shape tensor, rank 0 can run the stock evaluator on the full result set and no evaluator state crosses ranks.
+_ID_BITS = 21                                    # image ids travel as three 21-bit limbs: exact in f32, ids < 2^63
+
+
+def pack_detections_with_ids(image_ids, scores, labels, boxes):
+    """(B,) int64 ids + detections -> (B, K+1, 6) f32: row 0 carries the id (three 21-bit limbs), rows 1.. the detections.
+    The ids ride in the same all-gather as the detections - still ONE collective on the data path."""
+    ids = image_ids.to(torch.int64).to(scores.device)
+    if bool((ids < 0).any()):
+        raise ValueError("image ids must be non-negative")
+    mask = (1 << _ID_BITS) - 1
+    head = torch.zeros(ids.shape[0], 1, 6, dtype=torch.float32, device=scores.device)
+    head[:, 0, 0] = (ids & mask).float()
+    head[:, 0, 1] = ((ids >> _ID_BITS) & mask).float()
+    head[:, 0, 2] = (ids >> (2 * _ID_BITS)).float()
+    return torch.cat([head, pack_detections(scores, labels, boxes)], 1).contiguous()
+
+
+def unpack_detections_with_ids(packed):
+    head = packed[:, 0].to(torch.int64)
+    ids = head[:, 0] | (head[:, 1] << _ID_BITS) | (head[:, 2] << (2 * _ID_BITS))
+    return (ids,) + tuple(unpack_detections(packed[:, 1:]))
+
+
+def to_coco_results(image_ids, scores, labels, boxes):
+    """-> the list of dicts ``CocoEvaluator.prepare_for_coco_detection`` builds (datasets/coco_eval.py:91-113):
+    xyxy -> xywh (``convert_to_xywh``, :176-178), python scalars. Accepts the gathered tensors of the whole job."""
+    xywh = torch.stack([boxes[..., 0], boxes[..., 1], boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]], -1)
+    ids, sc, lb, bx = image_ids.tolist(), scores.tolist(), labels.tolist(), xywh.tolist()
+    return [{"image_id": ids[i], "category_id": lb[i][k], "bbox": bx[i][k], "score": sc[i][k]}
+            for i in range(len(ids)) for k in range(len(sc[i]))]
+
+
+def to_evaluator_update(image_ids, scores, labels, boxes):
+    """-> ``{image_id: {"scores", "labels", "boxes"}}``, the ``res`` dict ``engine.evaluate`` passes to
+    ``coco_evaluator.update`` (engine.py:153-155)."""
+    return {int(i): {"scores": s, "labels": l, "boxes": b} for i, s, l, b in zip(image_ids.tolist(), scores, labels, boxes)}
+
+
+def gather_for_evaluation(image_ids, scores, labels, boxes):
+    """Every rank contributes its shard (same b on every rank); returns the whole job's (ids, scores, labels, boxes) on
+    rank 0 and None elsewhere. Feed rank 0's result to ``to_evaluator_update`` / ``to_coco_results``."""
+    full = all_gather_detections(pack_detections_with_ids(image_ids, scores, labels, boxes))
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    return unpack_detections_with_ids(full) if rank == 0 else None

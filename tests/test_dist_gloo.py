@@ -69,3 +69,51 @@ def test_world_size_one_is_identity_and_shards_cover_batch():
         r = [D.shard_range(total, k, world) for k in range(world)]
         assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))
     assert D.init_from_env() == (0, 1, 0) or os.environ.get("WORLD_SIZE", "1") != "1"
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from lwdetr_amd import dist as D
+    D.init_from_env("gloo")
+    images, sizes, ids = _eval_job()
+    lo, hi = D.shard_range(images.shape[0], rank, world)
+    s, l, b = _fake_detect(images[lo:hi], sizes[lo:hi])
+    res = D.gather_for_evaluation(ids[lo:hi], s, l, b)
+    q.put((rank, None if res is None else D.to_coco_results(*res)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _eval_job():
+    g = torch.Generator().manual_seed(1)
+    images = torch.randn(8, 3, 4, 4, generator=g)
+    sizes = torch.tensor([[480.0, 640.0]] * 8)
+    ids = torch.tensor([139, 285, 632, 724, 581929, 2 ** 33 + 5, 0, 2 ** 45 + 123456789], dtype=torch.int64)   # COCO-like + huge
+    return images, sizes, ids
+
+
+def test_gathered_evaluation_results_on_rank0_equal_single_process():
+    """ids ride in the one all-gather; rank 0 ends up with exactly the COCO result list a single process
+    would build (reference datasets/coco_eval.py:91-113), other ranks with nothing."""
+    from lwdetr_amd import dist as D
+    images, sizes, ids = _eval_job()
+    s, l, b = _fake_detect(images, sizes)
+    exp = D.to_coco_results(*D.unpack_detections_with_ids(D.pack_detections_with_ids(ids, s, l, b)))
+    assert len(exp) == 8 * 5 and exp[0]["image_id"] == 139 and exp[-1]["image_id"] == 2 ** 45 + 123456789
+    box0 = b[0, 0].tolist()
+    assert exp[0]["bbox"] == pytest.approx([box0[0], box0[1], box0[2] - box0[0], box0[3] - box0[1]])
+    upd = D.to_evaluator_update(ids, s, l, b)
+    assert set(upd) == set(ids.tolist()) and torch.equal(upd[139]["boxes"], b[0])
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got[1] is None and got[0] == exp
