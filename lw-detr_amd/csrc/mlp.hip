@@ -52,6 +52,12 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, const vo
         (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(sbase) : "memory");
 }
+// wave-uniform pointer -> SGPR pair (for dma16's scalar base when uniformity is not provable, e.g. derived from the wave id)
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const uintptr_t v = (uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void*)(((uintptr_t)hi << 32) | lo);
+}
 __device__ __forceinline__ void dma_sync() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -86,6 +92,13 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     constexpr int W1_TILE_PAD = (W1_TILE + 64 * EPC - 1) / (64 * EPC) * (64 * EPC);   // whole 1 KB DMA pieces
     constexpr int W2_TILE_PAD = (W2_TILE + 64 * EPC - 1) / (64 * EPC) * (64 * EPC);
     constexpr int TILE_STRIDE = W1_TILE_PAD + W2_TILE_PAD;
+    // 16-bit C = 192 with the fused projection: the post-attention residual stream x1 of the workgroup's <= 7 tiles lives
+    // in LDS from the projection to the epilogue (x is DMA'd in, updated in place, read back by the epilogue) instead of
+    // going out to HBM and back: -39 MB of the kernel's 157 MB, no dependent global load in the projection loop, no store
+    // for the chunk barriers to drain. Rows are C + 8 elements (400 B == 36 dwords mod 64: the 16 rows of a ds_read_b64 /
+    // ds_write_b64 lane group start in 16 distinct even banks). The host deals at most X1_TILES tiles to a workgroup.
+    constexpr bool X1LDS = PROJ && sizeof(T) == 2 && C == 192;
+    constexpr int X1_LD = C + 8, X1_TILES = 7, X1_ELEMS = X1LDS ? X1_TILES * 16 * TT * X1_LD : 0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* smem = (T*)smem_raw;                    // [2][TILE_STRIDE] weight tiles, then fc1 bias (f32)
 
@@ -154,12 +167,15 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     // fc1 bias (and the projection's bias / LayerScale) -> LDS once: ordinary global loads inside the loops would force
     // an early drain of the DMA queue
     constexpr int XCHG = QKV ? NW * 16 * TT * (C + 2 * EPC) : 0;
-    float* b1s = (float*)(smem + (2 * TILE_STRIDE > XCHG ? 2 * TILE_STRIDE : XCHG));
+    T* x1s = smem + 2 * TILE_STRIDE + (wave < X1_TILES ? wave : 0) * 16 * TT * X1_LD;      // this wave's x1 rows (X1LDS)
+    float* b1s = (float*)(smem + (2 * TILE_STRIDE + X1_ELEMS > XCHG ? 2 * TILE_STRIDE + X1_ELEMS : XCHG));
     for (int i = tid; i < HID; i += NTHR) b1s[i] = p.b1[i];
     float* bps = b1s + HID;
     if (PROJ) for (int i = tid; i < C; i += NTHR) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; }
     float* bqs = bps + 2 * C;
     if (QKV) for (int i = tid; i < 3 * C; i += NTHR) bqs[i] = p.bqkv[i];
+    float* b2s = bqs + 3 * C;                    // fc2 bias and LayerScale (X1LDS: the epilogue issues no global load at all)
+    if (X1LDS) for (int i = tid; i < C; i += NTHR) { b2s[i] = p.b2[i]; b2s[C + i] = p.gamma2[i]; }
 
     // ---- prologue: token rows -> B-operand fragments xf (lane: token l15, 8 channels per k-chunk)
     V8 xf[TT][KC];
@@ -180,6 +196,19 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
         const T* __restrict__ ATT = (const T*)p.att;
         const T* __restrict__ WP = (const T*)p.wp;
         stage_rows32(WP, 0);
+        if (X1LDS && wave < X1_TILES) {
+            // this wave's 16 TT rows of x -> x1s: 25 sixteen-byte slots per row (24 data + 1 pad), lane-linear pieces
+            constexpr int SLOTS_ROW = X1_LD / 8, NSLOT = 16 * TT * SLOTS_ROW, NPIECE = (NSLOT + 63) / 64;
+            const long mw = m_wave < p.M ? m_wave : (p.M - 16 * TT > 0 ? p.M - 16 * TT : 0);   // idle waves: any valid rows
+            const void* xbase = uniform_ptr(X + mw * p.ldx);
+#pragma unroll
+            for (int k = 0; k < NPIECE; ++k) {
+                const int slot = k * 64 + lane, row = slot / SLOTS_ROW, c = slot - row * SLOTS_ROW;
+                long m = mw + row; m = m < p.M ? m : p.M - 1;
+                const unsigned off = (row < 16 * TT && c < C / 8) ? (unsigned)(((m - mw) * p.ldx + c * 8) * (long)sizeof(T)) : 0u;
+                if (slot < NSLOT) dma16(xbase, off, x1s + k * 64 * 8);      // last piece: only the lanes inside this wave's rows
+            }
+        }
         V8 af[TT][KC];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -216,8 +245,15 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
                 for (int t = 0; t < TT; ++t) {
                     const long m = m_wave + t * 16 + l15;
                     const long mr = m < p.M ? m : p.M - 1;
-                    const V4 x1 = cvt4<T>(up4<T>(*(const V4*)(X + mr * p.ldx + c0)) + gg * (accp[h][t] + bb));
-                    if (m < p.M) *(V4*)(X + m * p.ldx + c0) = x1;
+                    V4 x1;
+                    if (X1LDS) {
+                        T* xs = x1s + (t * 16 + l15) * X1_LD + c0;
+                        x1 = cvt4<T>(up4<T>(*(const V4*)xs) + gg * (accp[h][t] + bb));
+                        if (wave < X1_TILES) *(V4*)xs = x1;          // wave 7 never owns a tile (and has no rows of its own)
+                    } else {
+                        x1 = cvt4<T>(up4<T>(*(const V4*)(X + mr * p.ldx + c0)) + gg * (accp[h][t] + bb));
+                        if (m < p.M) *(V4*)(X + m * p.ldx + c0) = x1;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xf[t][pc][h * 4 + e] = x1[e];
                 }
@@ -327,8 +363,9 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int c0 = n * 16 + g * 4;
-            const f32x4 b2 = *(const f32x4*)(p.b2 + c0), g2 = *(const f32x4*)(p.gamma2 + c0);
-            const f32x4 xr = up4<T>(*(const V4*)(X + mr * p.ldx + c0));
+            const f32x4 b2 = X1LDS ? *(const f32x4*)(b2s + c0) : *(const f32x4*)(p.b2 + c0);
+            const f32x4 g2 = X1LDS ? *(const f32x4*)(b2s + C + c0) : *(const f32x4*)(p.gamma2 + c0);
+            const f32x4 xr = up4<T>(X1LDS ? *(const V4*)(x1s + (t * 16 + l15) * X1_LD + c0) : *(const V4*)(X + mr * p.ldx + c0));
             // round to the storage type now: the statistics below describe exactly what the next LayerNorm reads
             acc2[n][t] = up4<T>(cvt4<T>(xr + g2 * (acc2[n][t] + b2)));
         }
@@ -379,6 +416,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
         constexpr int NTQ = 3 * C / 16, NJ = (NTQ + NW - 1) / NW;
         const T* __restrict__ WQ = (const T*)p.wqkv;
         T* __restrict__ Qo = (T*)p.q; T* __restrict__ Ko = (T*)p.k; T* __restrict__ Vo = (T*)p.vt;
+        if (X1LDS) __syncthreads();      // the exchange area overlays the x1 rows: every wave is done reading its own
         constexpr int FRAG_REGS = KC * (int)sizeof(V8) / 4;
         constexpr int JP = (120 / FRAG_REGS) < 1 ? 1 : ((120 / FRAG_REGS) > NJ ? NJ : (120 / FRAG_REGS));   // tiles per pass
 #pragma unroll
@@ -461,7 +499,10 @@ int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     constexpr int W1P = (32 * (C + 2 * EPC) + PIECE - 1) / PIECE * PIECE, W2P = (C * (32 + 2 * EPC) + PIECE - 1) / PIECE * PIECE;
     constexpr size_t tiles_b = 2 * (size_t)(W1P + W2P) * sizeof(T);
     constexpr size_t xchg_b = QKV ? (size_t)NW * 16 * TT * (C + 2 * EPC) * sizeof(T) : 0;
-    constexpr size_t lds = (tiles_b > xchg_b ? tiles_b : xchg_b) + 9 * C * sizeof(float);
+    constexpr bool X1LDS = PROJ && sizeof(T) == 2 && C == 192;
+    constexpr int X1_TILES = 7;
+    constexpr size_t x1_b = X1LDS ? (size_t)X1_TILES * 16 * TT * (C + 8) * sizeof(T) : 0;
+    constexpr size_t lds = (tiles_b + x1_b > xchg_b ? tiles_b + x1_b : xchg_b) + (9 + (X1LDS ? 2 : 0)) * C * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -477,7 +518,8 @@ int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     MlpParams q = p;
     q.ntiles = (int)((p.M + 16 * TT - 1) / (16 * TT));
     long blocks = q.ntiles < ncu ? q.ntiles : ncu;                       // one workgroup per CU, tiles dealt evenly
-    if ((long)q.ntiles > blocks * NW) blocks = (q.ntiles + NW - 1) / NW;   // more than 8 tiles per CU: extra rounds
+    constexpr int TPW = X1LDS ? X1_TILES : NW;                          // tiles a workgroup can take (X1LDS: LDS rows for 7)
+    if ((long)q.ntiles > blocks * TPW) blocks = (q.ntiles + TPW - 1) / TPW;   // more than that per CU: extra rounds
     ProfScope ps(KID_MLP, (16.0 + (PROJ ? 2.0 : 0.0) + (QKV ? 6.0 : 0.0)) * p.M * C * C,
                  (double)p.M * C * sizeof(T) * (PROJ ? 3 : 2) + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T), st);
     hipLaunchKernelGGL((mlp_kernel<T, C, TT, PROJ, QKV>), dim3((unsigned)blocks), dim3(NTHR), lds, st, q);
