@@ -359,13 +359,16 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];      // zero p
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int AMODE, int NST>
+// KB = k-depth of a stage: 32 (a DMA piece = 16 rows x 64 B) or 64 (8 rows x 128 B: whole cache lines, half the
+// barriers / waits / address updates per byte; slot c of row r lives at slot c ^ ((r >> 1) & (KB / 8 - 1))).
+template <typename T, int BM, int BN, int AMODE, int NST, int KB = 32>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d) {
     constexpr int EPC = 8;
-    constexpr int A_MY = BM / 16 / 4, B_MY = BN / 16 / 4;        // DMA pieces (64 slots = 16 rows) per wave and operand
+    constexpr int SLOTS = KB / EPC, RP = 64 / SLOTS, KC = KB / 32;   // 16-byte slots per row, rows per DMA piece, MFMA k-chunks
+    constexpr int A_MY = BM / RP / 4, B_MY = BN / RP / 4;        // DMA pieces (64 slots) per wave and operand
     constexpr int PER_TILE = A_MY + B_MY;
     constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
-    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int STAGE = (BM + BN) * KB;
     typedef typename Vec<T>::v8 V8;
     static_assert(sizeof(T) == 2, "DMA variant is instantiated for f16 / bf16");
     constexpr int LDS_ELEMS = NST * STAGE > 64 * (BN + 4) * 2 ? NST * STAGE : 64 * (BN + 4) * 2;   // ring, or f32 staging
@@ -388,13 +391,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
     const T* __restrict__ W = (const T*)d.W;
     const T* zero = (const T*)g_zero16;
 
-    // lane -> (row inside a 16-row piece, logical 16-byte column); the swizzle makes the column lane-constant
-    const int prow = lane >> 2, ccol = ((lane & 3) ^ ((lane >> 3) & 3)) * EPC;
-    const T* a_src[A_MY]; int a_b[A_MY], a_y[A_MY], a_x[A_MY];
+    // lane -> (row inside a piece, physical slot); the logical 16-byte column a lane fetches is the slot un-swizzled with
+    // the row's key (piece i starts at row RP * i, so for KB = 64 the key also depends on the parity of i)
+    const int prow = lane / SLOTS, pslot = lane % SLOTS;
+    auto ccol_of = [&](int piece) { return (pslot ^ ((((piece * RP) + prow) >> 1) & (SLOTS - 1))) * EPC; };
+    const T* a_src[A_MY]; int a_b[A_MY], a_y[A_MY], a_x[A_MY], a_cc[A_MY];
 #pragma unroll
     for (int k = 0; k < A_MY; ++k) {
-        const long m = m0 + 16 * (wave + 4 * k) + prow;
-        a_src[k] = nullptr; a_b[k] = -1; a_y[k] = 0; a_x[k] = 0;
+        const long m = m0 + RP * (wave + 4 * k) + prow;
+        const int ccol = ccol_of(wave + 4 * k);
+        a_src[k] = nullptr; a_b[k] = -1; a_y[k] = 0; a_x[k] = 0; a_cc[k] = ccol;
         if (m < d.M) {
             if (AMODE == LWDETR_A_PLAIN) a_src[k] = A + m * d.lda + ccol;
             else if (AMODE == LWDETR_A_CONV3x3) {
@@ -410,17 +416,17 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
     const T* w_src[B_MY];
 #pragma unroll
     for (int k = 0; k < B_MY; ++k) {
-        const int n = n0 + 16 * (wave + 4 * k) + prow;
-        w_src[k] = n < d.N ? W + (long)n * d.K + ccol : nullptr;
+        const int n = n0 + RP * (wave + 4 * k) + prow;
+        w_src[k] = n < d.N ? W + (long)n * d.K + ccol_of(wave + 4 * k) : nullptr;
     }
-    const int nk = d.K / BK;
+    const int nk = d.K / KB;
     const T* conv_src[A_MY]; int conv_tap[A_MY];
 #pragma unroll
     for (int k = 0; k < A_MY; ++k) { conv_src[k] = nullptr; conv_tap[k] = -1; }
     auto stage = [&](int kt) {           // always PER_TILE pieces; tiles past the end of K read the zero page
         T* As = smem + (kt % NST) * STAGE;
-        T* Bs = As + BM * BK;
-        const int k0 = kt * BK;
+        T* Bs = As + BM * KB;
+        const int k0 = kt * KB;
         const bool live = kt < nk;
 #pragma unroll
         for (int k = 0; k < A_MY; ++k) {
@@ -430,16 +436,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
             } else if (AMODE == LWDETR_A_CONV3x3) {
                 // the shifted source row only changes with the tap (every Cin / 32 stages): its address (bounds test,
                 // token encode: ~40 VALU instructions per piece) is kept across the stages of a tap
-                const int tap = k0 / d.conv_cin;                    // uniform: Cin % 32 == 0
+                const int tap = k0 / d.conv_cin;                    // uniform: Cin % KB == 0
                 if (tap != conv_tap[k]) {
                     conv_tap[k] = tap;
                     const int iy = a_y[k] * d.conv_stride + tap / 3 - 1, ix = a_x[k] * d.conv_stride + tap % 3 - 1;
                     conv_src[k] = (a_b[k] >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp)
-                                      ? A + tok_encode(a_b[k], iy, ix, d.a_tok) * d.lda + d.a_col0 + ccol : nullptr;
+                                      ? A + tok_encode(a_b[k], iy, ix, d.a_tok) * d.lda + d.a_col0 + a_cc[k] : nullptr;
                 }
                 if (live && conv_src[k]) src = conv_src[k] + (k0 - tap * d.conv_cin);
             } else {
-                const int kk = k0 + ccol, ch = kk >> 8, py = (kk >> 4) & 15, px = kk & 15;
+                const int kk = k0 + a_cc[k], ch = kk >> 8, py = (kk >> 4) & 15, px = kk & 15;
                 if (live && a_b[k] >= 0)
                     src = A + (((long)a_b[k] * 3 + ch) * d.img_h + a_y[k] * 16 + py) * d.img_w + a_x[k] * 16 + px;
             }
@@ -466,7 +472,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int pc = (g ^ ((l15 >> 1) & 3)) * EPC;       // swizzled slot of this lane's k-run
+    int pc[KC];                                        // swizzled slots of this lane's k-runs
+#pragma unroll
+    for (int c = 0; c < KC; ++c) pc[c] = ((c * 4 + g) ^ ((l15 >> 1) & (SLOTS - 1))) * EPC;
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) stage(s);
     for (int kt = 0; kt < nk; ++kt) {
@@ -474,22 +482,28 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
         __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody also left tile kt-1's buffer
         stage(kt + NST - 1);                           // refill the buffer tile kt-1 used
         const T* As = smem + (kt % NST) * STAGE;
-        const T* Bs = As + BM * BK;
-        V8 xf[TT], wf[FT];
+        const T* Bs = As + BM * KB;
+        V8 xf[KC][TT], wf[KC][FT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) xf[t] = *(const V8*)(As + (wm * WM + t * 16 + l15) * BK + pc);
+        for (int c = 0; c < KC; ++c) {
 #pragma unroll
-        for (int f = 0; f < FT; ++f) wf[f] = *(const V8*)(Bs + (wn * WN + f * 16 + l15) * BK + pc);
-        if (!col_orient) {
+            for (int t = 0; t < TT; ++t) xf[c][t] = *(const V8*)(As + (wm * WM + t * 16 + l15) * KB + pc[c]);
 #pragma unroll
-            for (int f = 0; f < FT; ++f)
+            for (int f = 0; f < FT; ++f) wf[c][f] = *(const V8*)(Bs + (wn * WN + f * 16 + l15) * KB + pc[c]);
+        }
 #pragma unroll
-                for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(wf[f], xf[t], acc[f][t]);
-        } else {
+        for (int c = 0; c < KC; ++c) {
+            if (!col_orient) {
 #pragma unroll
-            for (int f = 0; f < FT; ++f)
+                for (int f = 0; f < FT; ++f)
 #pragma unroll
-                for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(xf[t], wf[f], acc[f][t]);
+                    for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(wf[c][f], xf[c][t], acc[f][t]);
+            } else {
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(xf[c][t], wf[c][f], acc[f][t]);
+            }
         }
     }
     __syncthreads();            // drains the dummy tail pieces and the last fragment reads before LDS is re-used
@@ -529,7 +543,12 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
         static const char* env = getenv("LWDETR_GEMM_DMA");
         const int mode = env ? atoi(env) : 3;
         if (mode && !d.A2) {
-            if (small) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            // 64-deep stages measured equal to 32-deep ones on every GEMM of the network (0.879 vs 0.880 ms per step): the
+            // k-loop is not where these short-K GEMMs spend their time. Kept selectable for tuning (LWDETR_GEMM_KB=64).
+            static const char* kb_env = getenv("LWDETR_GEMM_KB");
+            const bool kb64 = kb_env && atoi(kb_env) == 64 && d.K % 64 == 0 && (AMODE != LWDETR_A_CONV3x3 || d.conv_cin % 64 == 0);
+            if (small && kb64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3, 64>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            else if (small) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else if (bn64) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else if (mode == 4) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, AMODE, 3>), dim3((unsigned)nwg), dim3(256), 0, st, d);
