@@ -510,6 +510,130 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
     gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, smem, m0, n0);
 }
 
+// ---- A-panel-resident variant (16-bit, plain A, K <= 768): one workgroup owns BM rows and ALL N columns. The BM x K panel
+// of A is DMA'd into LDS once and stays; the weight matrix streams through an NST-deep ring of 64 x 64 stages while the
+// workgroup walks the column tiles. Why: these GEMMs have short K and are bound by what a CU can pull in per output tile -
+// a 64 x 64 tile re-fetches its A rows for every column tile (N / 64 times) and its W rows for every row tile; here A
+// enters a CU once and W once per BM rows (QKV of block 0, M = 51200, N = 576, K = 192: 108 MB of CU ingress instead of
+// 345 MB). LDS image: K / 64 column blocks of [BM][64], each swizzled exactly like a KB = 64 stage of gemm_dma_kernel.
+// The DMA goes through inline assembly (untracked by hipcc, see mlp.hip) and is drained by counted waits; the epilogue's
+// global stores share vmcnt with it and loads / stores may retire out of order, so the first wait after an epilogue drains
+// the counter completely (the ring pieces in flight have had the whole epilogue to land).
+__device__ __forceinline__ void gdma16(const void* src, const void* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
+}
+
+template <typename T, int BM, int NST>
+__global__ __launch_bounds__(256) void gemm_apanel_kernel(const lwdetr_gemm_desc d) {
+    constexpr int EPC = 8, BN = 64, KB = 64, SLOTS = 8, RP = 8;
+    constexpr int A_MY = BM / RP / 4, B_MY = BN / RP / 4;        // DMA pieces per wave: per A column block / per W stage
+    constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
+    constexpr int STAGE = BN * KB;
+    typedef typename Vec<T>::v8 V8;
+    static_assert(sizeof(T) == 2, "");
+    extern __shared__ __attribute__((aligned(16))) char apanel_smem[];
+    T* panel = (T*)apanel_smem;                                  // [K / 64][BM][64]
+    const int nkb = d.K / KB;
+    T* ring = panel + (long)nkb * BM * KB;                       // [NST][BN][64]
+    T* stage_area = ring + NST * STAGE;                          // f32 epilogue staging, 64 x (BN + 4) floats
+
+    const long m0 = (long)blockIdx.x * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const T* __restrict__ A = (const T*)d.A;
+    const T* __restrict__ W = (const T*)d.W;
+    const T* zero = (const T*)g_zero16;
+    const int prow = lane / SLOTS, pslot = lane % SLOTS;
+
+    // ---- A panel: every column block, this wave's pieces
+#pragma unroll
+    for (int k = 0; k < A_MY; ++k) {
+        const int piece = wave + 4 * k;
+        const long m = m0 + RP * piece + prow;
+        const int ccol = (pslot ^ (((piece * RP + prow) >> 1) & 7)) * EPC;
+        const T* src = m < d.M ? A + m * d.lda + ccol : nullptr;
+        for (int kb = 0; kb < nkb; ++kb)
+            gdma16(src ? src + kb * KB : zero, panel + ((long)kb * BM + piece * RP) * KB);
+    }
+    // ---- W ring: stage s = (column tile tn, column block kb) in walking order
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int nstage = tiles_n * nkb;
+    int w_cc[B_MY], w_row[B_MY];
+#pragma unroll
+    for (int k = 0; k < B_MY; ++k) {
+        const int piece = wave + 4 * k;
+        w_cc[k] = (pslot ^ (((piece * RP + prow) >> 1) & 7)) * EPC;
+        w_row[k] = RP * piece + prow;
+    }
+    auto stage = [&](int s) {            // always B_MY pieces; stages past the end read the zero page
+        T* Bs = ring + (s % NST) * STAGE;
+        const int tn = s / nkb, kb = s - tn * nkb;
+#pragma unroll
+        for (int k = 0; k < B_MY; ++k) {
+            const int n = tn * BN + w_row[k];
+            const T* src = (s < nstage && n < d.N) ? W + (long)n * d.K + kb * KB + w_cc[k] : zero;
+            gdma16(src, Bs + (wave + 4 * k) * 64 * EPC);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) stage(s);
+
+    int pc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) pc[c] = ((c * 4 + g) ^ ((l15 >> 1) & 7)) * EPC;
+    bool drained = false;                // true right after an epilogue: stores are in flight, counted waits are unsafe
+    int s = 0;
+    for (int tn = 0; tn < tiles_n; ++tn) {
+        const int n0 = tn * BN;
+        int si = 0;
+#pragma unroll
+        for (int q = 1; q < 3; ++q) if (q < d.nseg && n0 >= d.seg[q].n_begin) si = q;
+        const lwdetr_gemm_seg& sg = d.seg[si];
+        const bool col_orient = sg.mode == LWDETR_OUT_HEADS_T;
+        f32x4 acc[FT][TT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nkb; ++kb, ++s) {
+            if (drained || s == 0) { wait_vmcnt<0>(); drained = false; }      // s == 0: the A panel too (issued first anyway)
+            else wait_vmcnt<(NST - 2) * B_MY>();
+            __builtin_amdgcn_s_barrier();
+            stage(s + NST - 1);
+            const T* As = panel + (long)kb * BM * KB;
+            const T* Bs = ring + (s % NST) * STAGE;
+            V8 xf[2][TT], wf[2][FT];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int t = 0; t < TT; ++t) xf[c][t] = *(const V8*)(As + (wm * WM + t * 16 + l15) * KB + pc[c]);
+#pragma unroll
+                for (int f = 0; f < FT; ++f) wf[c][f] = *(const V8*)(Bs + (wn * WN + f * 16 + l15) * KB + pc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (!col_orient) {
+#pragma unroll
+                    for (int f = 0; f < FT; ++f)
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(wf[c][f], xf[c][t], acc[f][t]);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < FT; ++f)
+#pragma unroll
+                        for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(xf[c][t], wf[c][f], acc[f][t]);
+                }
+            }
+        }
+        gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, stage_area, m0, n0);
+        drained = true;
+    }
+    wait_vmcnt<0>();                     // the dummy tail pieces target LDS: they must land before the workgroup retires
+}
+
 template <typename T, int AMODE>
 int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     // column tile: 128 unless a segment boundary (or a small N) asks for 64
@@ -547,6 +671,32 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
             // k-loop is not where these short-K GEMMs spend their time. Kept selectable for tuning (LWDETR_GEMM_KB=64).
             static const char* kb_env = getenv("LWDETR_GEMM_KB");
             const bool kb64 = kb_env && atoi(kb_env) == 64 && d.K % 64 == 0 && (AMODE != LWDETR_A_CONV3x3 || d.conv_cin % 64 == 0);
+            // A-panel-resident schedule (LWDETR_GEMM_APANEL=64|128 selects it and its row tile; OFF by default). Measured on
+            // MI355X, M = 51200: QKV (N 576, K 192) 51 -> 73 / 106 us, projector 1x1 (N 256, K 768) 60 -> 137 us, value
+            // projection (N 768, K 256) 62 -> 93 / 124 us. It cuts what a CU pulls in by 2-3x and loses anyway: with 66-108 KB
+            // of LDS a CU holds one or two workgroups, whose column tiles, epilogues and store latencies then run back to
+            // back, where the 64 x 64 grid keeps 4-5 independent workgroups per CU in flight. These GEMMs are bound by
+            // latency hiding (occupancy), not by CU ingress.
+            static const char* ap_env = getenv("LWDETR_GEMM_APANEL");
+            const bool ap_ok = AMODE == LWDETR_A_PLAIN && d.K % 64 == 0 && d.K <= 768 && d.N > 64 && d.M >= 32768 &&
+                               ap_env && (atoi(ap_env) == 64 || atoi(ap_env) == 128);
+            if (ap_ok) {
+                const int bm_env = ap_env ? atoi(ap_env) : 0;
+                const int bm = (bm_env == 64 || bm_env == 128) && (size_t)d.K * bm_env * sizeof(T) <= 100 * 1024 ? bm_env
+                                                                                                              : (d.K <= 384 ? 128 : 64);
+                const size_t lds = ((size_t)d.K * bm + 3 * 64 * 64) * sizeof(T) + 64 * (64 + 4) * sizeof(float);
+                const unsigned blocks = (unsigned)((d.M + bm - 1) / bm);
+                if (bm == 128) {
+                    static bool done = false;
+                    if (!done) { if (hipFuncSetAttribute((const void*)gemm_apanel_kernel<T, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return LWDETR_ERR_LAUNCH; done = true; }
+                    hipLaunchKernelGGL((gemm_apanel_kernel<T, 128, 3>), dim3(blocks), dim3(256), lds, st, d);
+                } else {
+                    static bool done = false;
+                    if (!done) { if (hipFuncSetAttribute((const void*)gemm_apanel_kernel<T, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return LWDETR_ERR_LAUNCH; done = true; }
+                    hipLaunchKernelGGL((gemm_apanel_kernel<T, 64, 3>), dim3(blocks), dim3(256), lds, st, d);
+                }
+                return lwdetr_check_launch();
+            }
             if (small && kb64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3, 64>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else if (small) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else if (bn64) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);

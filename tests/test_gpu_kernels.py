@@ -27,7 +27,9 @@ def _relerr(a, b):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mnk", [(300, 192, 192), (1000, 91, 256), (257, 4, 256), (4096, 576, 192), (513, 768, 2048)])
+@pytest.mark.parametrize("mnk", [(300, 192, 192), (1000, 91, 256), (257, 4, 256), (4096, 576, 192), (513, 768, 2048),
+                                 # BASELINE row counts (32 images x 1600 tokens and a ragged one): the A-panel-resident schedule
+                                 (51200, 256, 768), (51200, 91, 256), (33001, 576, 192), (40000, 256, 640)])
 def test_gemm_linear_bias_act_res(dtype, mnk):
     from lwdetr_amd import kernels as K
     m, n, k = mnk
@@ -44,11 +46,12 @@ def test_gemm_linear_bias_act_res(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("hd", [16, 32, 64])
-def test_gemm_qkv_head_layouts(dtype, hd):
-    """Three column segments: Q (HEADS, bias, scale), K (HEADS), V^T (HEADS_T, bias) - transpose-detecting data."""
+@pytest.mark.parametrize("hd,b,tp", [(16, 2, 104), (32, 2, 104), (64, 2, 104), (16, 32, 1600), (32, 24, 1600)])
+def test_gemm_qkv_head_layouts(dtype, hd, b, tp):
+    """Three column segments: Q (HEADS, bias, scale), K (HEADS), V^T (HEADS_T, bias) - transpose-detecting data.
+    The (32, 1600) / (24, 1600) cases are full-size batches (block 0 of small / medium: A-panel-resident schedule)."""
     from lwdetr_amd import kernels as K
-    heads, b, tp = 12, 2, 104
+    heads = 12
     c = heads * hd
     x = _rand(b * tp, c, dtype=dtype, seed=1)
     w = _rand(3 * c, c, dtype=dtype, scale=c ** -0.5, seed=2)
