@@ -698,7 +698,15 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
                 return lwdetr_check_launch();
             }
             if (small && kb64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3, 64>), dim3((unsigned)nwg), dim3(256), 0, st, d);
-            else if (small) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            else if (small) {
+                // ring depth of the 64 x 64 kernel trades prefetch distance against workgroups per CU (24 KB of LDS at depth 3:
+                // six per CU). Measured on the whole network: depth 4 0.894 ms, depth 3 0.847 ms, depth 2 0.868 ms per step.
+                static const char* nst_env = getenv("LWDETR_GEMM_NST");
+                const int nst = nst_env ? atoi(nst_env) : 3;
+                if (nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 2>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+                else if (nst == 3) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+                else hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+            }
             else if (bn64) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else if (mode == 4) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, AMODE, 3>), dim3((unsigned)nwg), dim3(256), 0, st, d);
