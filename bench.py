@@ -204,8 +204,9 @@ def main():
         result["cpu_baseline"] = cpu_baseline(a.size, a.res)
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        torch.distributed.barrier()          # rank 0 may still be in its (untimed) roofline pass: leave together
         torch.distributed.destroy_process_group()
 
 
