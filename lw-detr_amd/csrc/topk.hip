@@ -26,9 +26,8 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
 
-template <typename T>
-__device__ __forceinline__ unsigned long long tk_comp(const T* __restrict__ x, int i) {
-    return ((unsigned long long)fkey(to_f32<T>(x[i])) << TK_IDX_BITS) | (unsigned long long)(TK_IDX_MASK - (unsigned)i);
+__device__ __forceinline__ unsigned long long tk_comp(unsigned key, int i) {
+    return ((unsigned long long)key << TK_IDX_BITS) | (unsigned long long)(TK_IDX_MASK - (unsigned)i);
 }
 
 struct TopkShared {
@@ -39,23 +38,47 @@ struct TopkShared {
 };
 
 // Leaves the k winners' composites in sh.sel[0..k) and their descending ranks in sh.rank[0..k). All threads call it.
-template <typename T>
-__device__ void topk_block(const T* __restrict__ x, int N, int K, TopkShared& sh) {
+// CACHE: the 32-bit keys of the image are written to LDS (`keys`, N words of dynamic shared memory) by the first pass and
+// read from there by the later ones - one dependent L2 round trip per element instead of four or five.
+template <typename T, bool CACHE>
+__device__ void topk_block(const T* __restrict__ x, int N, int K, TopkShared& sh, unsigned* __restrict__ keys) {
     const int tid = threadIdx.x;
     unsigned long long prefix = 0;          // digits decided so far (the high bits of the threshold composite)
     unsigned rem = (unsigned)K;             // how many elements are still to be taken among those matching the prefix
     unsigned long long thr = 0;
     int top = 32 + TK_IDX_BITS;             // bits not yet decided
+    bool first = true;
     while (true) {
         const int bits = top > 30 ? 11 : 10;            // 52 = 11 + 11 + 10 + 10 + 10
         const int shift = top - bits;
         const unsigned nb = 1u << bits;
         for (int i = tid; i < 2048; i += TK_THREADS) sh.hist[i] = 0;
         __syncthreads();
-        for (int i = tid; i < N; i += TK_THREADS) {
-            const unsigned long long c = tk_comp<T>(x, i);
-            if ((c >> top) == prefix) atomicAdd(&sh.hist[(unsigned)(c >> shift) & (nb - 1)], 1u);
+        if (first) {
+            // the only pass that touches global memory (CACHE): 4 independent loads in flight per thread
+            int i = tid;
+            for (; i + 3 * TK_THREADS < N; i += 4 * TK_THREADS) {
+                unsigned k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) k4[u] = fkey(to_f32<T>(x[i + u * TK_THREADS]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (CACHE) keys[i + u * TK_THREADS] = k4[u];
+                    atomicAdd(&sh.hist[k4[u] >> 21], 1u);           // first digit = the top 11 of the 32 key bits
+                }
+            }
+            for (; i < N; i += TK_THREADS) {
+                const unsigned k = fkey(to_f32<T>(x[i]));
+                if (CACHE) keys[i] = k;
+                atomicAdd(&sh.hist[k >> 21], 1u);
+            }
+        } else {
+            for (int i = tid; i < N; i += TK_THREADS) {
+                const unsigned long long c = tk_comp(CACHE ? keys[i] : fkey(to_f32<T>(x[i])), i);
+                if ((c >> top) == prefix) atomicAdd(&sh.hist[(unsigned)(c >> shift) & (nb - 1)], 1u);
+            }
         }
+        first = false;
         __syncthreads();
         if (tid < 64) {                                  // wave 0: lane l owns bins [l * per, (l + 1) * per)
             const int per = (int)nb >> 6;
@@ -88,7 +111,7 @@ __device__ void topk_block(const T* __restrict__ x, int N, int K, TopkShared& sh
     for (int i = tid; i < TK_MAXK; i += TK_THREADS) sh.rank[i] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += TK_THREADS) {
-        const unsigned long long c = tk_comp<T>(x, i);
+        const unsigned long long c = tk_comp(CACHE ? keys[i] : fkey(to_f32<T>(x[i])), i);
         if (c >= thr) {
             const unsigned p = atomicAdd(&sh.nsel, 1u);
             if (p < (unsigned)K) sh.sel[p] = c;
@@ -108,12 +131,13 @@ __device__ void topk_block(const T* __restrict__ x, int N, int K, TopkShared& sh
     __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool CACHE>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ x, int N, int K, int64_t* __restrict__ idx_out,
                                                           float* __restrict__ val_out) {
     __shared__ TopkShared sh;
+    extern __shared__ unsigned tk_keys[];
     const int b = blockIdx.x;
-    topk_block<T>(x + (long)b * N, N, K, sh);
+    topk_block<T, CACHE>(x + (long)b * N, N, K, sh, tk_keys);
     const int tid = threadIdx.x;
     if (tid < K) {
         const unsigned long long c = sh.sel[tid];
@@ -124,15 +148,16 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const T* __restrict__ 
 }
 
 // PostProcess: sigmoid is monotone, so the top-k runs on the logits and only the k winners go through sigmoid.
-template <typename T>
+template <typename T, bool CACHE>
 __global__ __launch_bounds__(TK_THREADS) void postprocess_kernel(const T* __restrict__ logits, const T* __restrict__ boxes,
                                                                  const float* __restrict__ sizes, int nq, int ncls, int K,
                                                                  float* __restrict__ scores, int64_t* __restrict__ labels,
                                                                  float* __restrict__ out_boxes) {
     __shared__ TopkShared sh;
+    extern __shared__ unsigned tk_keys[];
     const int b = blockIdx.x;
     const int N = nq * ncls;
-    topk_block<T>(logits + (long)b * N, N, K, sh);
+    topk_block<T, CACHE>(logits + (long)b * N, N, K, sh, tk_keys);
     const int tid = threadIdx.x;
     if (tid < K) {
         const unsigned long long c = sh.sel[tid];
@@ -179,6 +204,17 @@ __global__ __launch_bounds__(256) void rowmax_kernel(const T* __restrict__ x, lo
 
 }  // namespace
 
+// key cache: whatever is left of the 160 KB beside TopkShared; larger inputs (e.g. 300 x 366 Objects365 logits) re-read global
+constexpr size_t TK_CACHE_BYTES = 160 * 1024 - sizeof(TopkShared) - 256;
+static bool tk_allow_lds(const void* fn) {
+    // once per kernel instantiation (keyed by its address); hipFuncSetAttribute is not a stream operation
+    static const void* done[16]; static int ndone = 0;
+    for (int i = 0; i < ndone; ++i) if (done[i] == fn) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_CACHE_BYTES) != hipSuccess) return false;
+    if (ndone < 16) done[ndone++] = fn;
+    return true;
+}
+
 #define LWDETR_DISPATCH_T(dtype, CALL)                 \
     switch (dtype) {                                   \
         case DT_F32: { typedef float TT; CALL; break; } \
@@ -203,8 +239,15 @@ extern "C" int lwdetr_topk(const void* x, int B, int N, int K, int64_t* idx_out,
     if (B == 0) return LWDETR_OK;
     hipStream_t st = (hipStream_t)hip_stream;
     ProfScope ps(KID_ELTWISE, 0.0, (double)B * N * (dtype == DT_F32 ? 4 : 2), st);
-    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((topk_kernel<TT>), dim3(B), dim3(TK_THREADS), 0, st, (const TT*)x, N, K, idx_out,
-                                                val_out));
+    const bool cache = (size_t)N * 4 <= TK_CACHE_BYTES;
+    LWDETR_DISPATCH_T(dtype, {
+        if (cache) {
+            if (!tk_allow_lds((const void*)topk_kernel<TT, true>)) return LWDETR_ERR_LAUNCH;
+            hipLaunchKernelGGL((topk_kernel<TT, true>), dim3(B), dim3(TK_THREADS), (size_t)N * 4, st, (const TT*)x, N, K, idx_out, val_out);
+        } else {
+            hipLaunchKernelGGL((topk_kernel<TT, false>), dim3(B), dim3(TK_THREADS), 0, st, (const TT*)x, N, K, idx_out, val_out);
+        }
+    });
     return lwdetr_check_launch();
 }
 
@@ -216,7 +259,17 @@ extern "C" int lwdetr_postprocess(const void* logits, const void* boxes, const f
     if (B == 0) return LWDETR_OK;
     hipStream_t st = (hipStream_t)hip_stream;
     ProfScope ps(KID_ELTWISE, 0.0, (double)B * nq * ncls * (dtype == DT_F32 ? 4 : 2), st);
-    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((postprocess_kernel<TT>), dim3(B), dim3(TK_THREADS), 0, st, (const TT*)logits,
-                                                (const TT*)boxes, target_sizes, nq, ncls, K, scores, labels, out_boxes));
+    const size_t kb = (size_t)nq * ncls * 4;
+    const bool cache = kb <= TK_CACHE_BYTES;
+    LWDETR_DISPATCH_T(dtype, {
+        if (cache) {
+            if (!tk_allow_lds((const void*)postprocess_kernel<TT, true>)) return LWDETR_ERR_LAUNCH;
+            hipLaunchKernelGGL((postprocess_kernel<TT, true>), dim3(B), dim3(TK_THREADS), kb, st, (const TT*)logits, (const TT*)boxes,
+                               target_sizes, nq, ncls, K, scores, labels, out_boxes);
+        } else {
+            hipLaunchKernelGGL((postprocess_kernel<TT, false>), dim3(B), dim3(TK_THREADS), 0, st, (const TT*)logits, (const TT*)boxes,
+                               target_sizes, nq, ncls, K, scores, labels, out_boxes);
+        }
+    });
     return lwdetr_check_launch();
 }
