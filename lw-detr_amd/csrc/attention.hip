@@ -297,7 +297,10 @@ int launch(const lwdetr_attn_desc& p, hipStream_t st) {
     // long sequences: 64 queries per wave (K / V^T fragments amortised over 4 query tiles); short ones keep 32 so a
     // 100-token window still spreads over 4 waves
     static const char* force = getenv("LWDETR_ATTN_QT");
-    const bool qt4 = force ? atoi(force) == 4 : (p.keys_per_seq >= 1024 && HD <= 32 && sizeof(T) == 2);
+    // ... and only when that still leaves at least one workgroup per CU (a single image has 84 of them at 64 queries per
+    // wave: 25 us per launch against 18 us with 32)
+    const long wgs4 = (long)((p.keys_per_seq + 255) / 256) * p.heads * p.B * p.seqs_per_img;
+    const bool qt4 = force ? atoi(force) == 4 : (p.keys_per_seq >= 1024 && HD <= 32 && sizeof(T) == 2 && wgs4 >= 256);
     if (qt4) return launch_qt<T, HD, (HD <= 32 ? 4 : 2)>(p, st);
     return launch_qt<T, HD, 2>(p, st);
 }
