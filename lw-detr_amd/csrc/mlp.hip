@@ -21,6 +21,7 @@
 //              (mean, rstd) of the NEW x for the next block's LayerNorm, which the QKV GEMM applies on load.
 // LDS row strides are == 2 (mod 4) sixteen-byte slots: conflict-free for the 16-lane ds_read_b128 service groups.
 #include "common.h"
+#include <cstdlib>
 
 #ifndef MLP_WAVES_PER_SIMD
 #define MLP_WAVES_PER_SIMD 2
@@ -492,6 +493,258 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     TSTAMP(6);
 }
 
+// ---- few-token variant (16-bit, C = 192, with the projection; a handful of images: the single-image latency path).
+// mlp_kernel gives a wave one tile and the whole hidden dimension: at 50 tiles that is 50 busy waves on the chip, each
+// walking 24 chunks alone (~70 us). Here ONE 32-token tile is a workgroup and its 8 waves split the work the other way:
+//   projection : waves 0-5 each produce 32 output channels of x1 (weights straight from L2 into A fragments) -> LDS
+//   LayerNorm  : every wave reads the whole x1 tile back as its B fragments (redundant, ~100 VALU)
+//   hidden     : wave w takes hidden chunks w, w + 8, w + 16 (3 of 24), weights straight from L2, partial fc2 sums
+//   reduction  : the 8 partial tiles are summed through LDS in two rounds of 6 channel tiles; waves 0-5 finish one channel
+//                tile each (bias, LayerScale, residual, stores) and put the new rows back into LDS
+//   chained QKV: every wave normalises the whole tile again and computes its share of the 36 feature tiles from registers.
+// No weight goes through LDS, no DMA ring, 6 barriers in all. Same packed weights and the same arithmetic per element as
+// the large kernel, except for the order in which the 24 partial sums of fc2 are added (f32).
+template <typename T, bool QKV>
+__global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
+    constexpr int C = 192, TT = 2, KC = C / 32, NT = C / 16, HID = 4 * C, X1_LD = C + 8;
+    typedef typename Vec<T>::v8 V8;
+    typedef typename Vec<T>::v4 V4;
+    static_assert(sizeof(T) == 2, "");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* x1s = (T*)smem_raw;                                        // [32][X1_LD]: x1, then the block's output rows
+    float* part = (float*)(x1s + 32 * X1_LD);                     // [8 waves][6 tiles][2][64 lanes][4]
+    float* b1s = part + NW * 6 * TT * 256;
+    float* bps = b1s + HID; float* bqs = bps + 2 * C; float* b2s = bqs + 3 * C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const long m0 = (long)blockIdx.x * (16 * TT);
+    T* __restrict__ X = (T*)p.x;
+    const T* __restrict__ W1 = (const T*)p.w1;
+    const T* __restrict__ W2 = (const T*)p.w2p;
+    for (int i = tid; i < HID; i += NTHR) b1s[i] = p.b1[i];
+    for (int i = tid; i < C; i += NTHR) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; b2s[i] = p.b2[i]; b2s[C + i] = p.gamma2[i]; }
+    if (QKV) for (int i = tid; i < 3 * C; i += NTHR) bqs[i] = p.bqkv[i];
+    long mrow[TT]; bool mok[TT];                                  // this lane's token rows (clamped for loads)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { const long m = m0 + t * 16 + l15; mok[t] = m < p.M; mrow[t] = mok[t] ? m : p.M - 1; }
+    __syncthreads();                                              // biases visible
+
+    // ---- projection: wave pc < 6 -> channels 32 pc .. 32 pc + 31 of x1 = x + gamma1 * (att Wp^T + bp)
+    if (wave < KC) {
+        const int pc = wave;
+        const T* __restrict__ ATT = (const T*)p.att;
+        const T* __restrict__ WP = (const T*)p.wp;
+        V8 af[TT][KC], wa[2][KC];
+        V4 xr[2][TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) af[t][kc] = *(const V8*)(ATT + mrow[t] * p.ldatt + kc * 32 + g * 8);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) wa[h][kc] = *(const V8*)(WP + (long)(pc * 32 + h * 16 + l15) * C + kc * 32 + g * 8);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) xr[h][t] = *(const V4*)(X + mrow[t] * p.ldx + pc * 32 + h * 16 + g * 4);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c0 = pc * 32 + h * 16 + g * 4;
+            const f32x4 bb = *(const f32x4*)(bps + c0), gg = *(const f32x4*)(bps + C + c0);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) a = Mma<T>::k32(wa[h][kc], af[t][kc], a);
+                *(V4*)(x1s + (t * 16 + l15) * X1_LD + c0) = cvt4<T>(up4<T>(xr[h][t]) + gg * (a + bb));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- every wave: the whole x1 tile as B fragments (k-slot order of the projection's accumulators), LayerNorm
+    V8 xf[TT][KC];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const V4 v = *(const V4*)(x1s + (t * 16 + l15) * X1_LD + kc * 32 + h * 16 + g * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xf[t][kc][h * 4 + e] = v[e];
+            }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float sm = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm += to_f32<T>(xf[t][kc][e]);
+        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        const float mean = sm * (1.f / C);
+        float v = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = to_f32<T>(xf[t][kc][e]) - mean; v += dl * dl; }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[t][kc][e] = from_f32<T>((to_f32<T>(xf[t][kc][e]) - mean) * rstd);
+    }
+
+    // ---- hidden chunks wave, wave + 8, wave + 16
+    f32x4 acc2[NT][TT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc2[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int hc = wave; hc < HID / 32; hc += NW) {
+        V8 fr[2 * KC];
+#pragma unroll
+        for (int i = 0; i < 2 * KC; ++i)        // fc1 fragment i = (kc = i / 2, h = i % 2)
+            fr[i] = *(const V8*)(W1 + (long)(hc * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
+        const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
+        f32x4 acc1[2][TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { acc1[0][t] = bia0; acc1[1][t] = bia1; }
+#pragma unroll
+        for (int i = 0; i < 2 * KC; ++i)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc1[i & 1][t] = Mma<T>::k32(fr[i], xf[t][i >> 1], acc1[i & 1][t]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)            // fc2 fragments of the chunk: in flight while GELU runs
+            fr[n] = *(const V8*)(W2 + (long)hc * 32 * C + (n * 16 + l15) * 32 + g * 8);
+        V8 hf[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hf[t][e] = from_f32<T>(gelu_for<T>(acc1[0][t][e]));
+                hf[t][4 + e] = from_f32<T>(gelu_for<T>(acc1[1][t][e]));
+            }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc2[n][t] = Mma<T>::k32(fr[n], hf[t], acc2[n][t]);
+    }
+
+    // ---- reduction over the 8 waves + epilogue, 6 channel tiles per round; wave w < 6 finishes channel tile 6 r + w
+    T* __restrict__ O2 = (T*)p.out2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) *(f32x4*)(part + ((wave * 6 + n) * TT + t) * 256 + lane * 4) = acc2[6 * r + n][t];
+        __syncthreads();
+        if (wave < 6) {
+            const int c0 = (6 * r + wave) * 16 + g * 4;
+            const f32x4 b2 = *(const f32x4*)(b2s + c0), g2 = *(const f32x4*)(b2s + C + c0);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                f32x4 sum = *(const f32x4*)(part + ((0 * 6 + wave) * TT + t) * 256 + lane * 4);
+#pragma unroll
+                for (int w = 1; w < NW; ++w) sum += *(const f32x4*)(part + ((w * 6 + wave) * TT + t) * 256 + lane * 4);
+                T* xs = x1s + (t * 16 + l15) * X1_LD + c0;
+                const V4 o = cvt4<T>(up4<T>(*(const V4*)xs) + g2 * (sum + b2));
+                *(V4*)xs = o;
+                if (mok[t]) {
+                    *(V4*)(X + mrow[t] * p.ldx + c0) = o;
+                    if (O2) *(V4*)(O2 + mrow[t] * p.ld2 + c0) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!(p.stats_out || QKV)) return;
+    // ---- statistics of the new rows (every wave, from LDS) and the chained LayerNorm + QKV of the next block
+    V8 xq[TT][KC];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float xv[KC][8];
+        float sm = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const V4 v = *(const V4*)(x1s + (t * 16 + l15) * X1_LD + kc * 32 + h * 16 + g * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xv[kc][h * 4 + e] = to_f32<T>(v[e]); sm += xv[kc][h * 4 + e]; }
+            }
+        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        const float mean = sm * (1.f / C);
+        float v = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = xv[kc][e] - mean; v += dl * dl; }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps_next);
+        if (p.stats_out && wave == 0 && mok[t] && g == 0) { p.stats_out[2 * mrow[t]] = mean; p.stats_out[2 * mrow[t] + 1] = rstd; }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xq[t][kc][e] = from_f32<T>((xv[kc][e] - mean) * rstd);
+    }
+    if (!QKV) return;
+    // Q, K: D[feature][token] -> (B, heads, Tp, hd); V: operands swapped, D[token][feature] -> V^T (B, heads, hd, Tp)
+    constexpr int NTQ = 3 * C / 16;
+    const T* __restrict__ WQ = (const T*)p.wqkv;
+    T* __restrict__ Qo = (T*)p.q; T* __restrict__ Ko = (T*)p.k; T* __restrict__ Vo = (T*)p.vt;
+#pragma unroll 1
+    for (int nt = wave; nt < NTQ; nt += NW) {
+        V8 wq[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) wq[kc] = *(const V8*)(WQ + (long)(nt * 16 + l15) * C + kc * 32 + g * 8);
+        const int sg = nt / (C / 16), nl0 = (nt - sg * (C / 16)) * 16;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            if (sg < 2) {
+                const int nl = nl0 + g * 4, hh = nl / p.hd, dd = nl - hh * p.hd;
+                f32x4 acc = *(const f32x4*)(bqs + sg * C + nl);
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(wq[kc], xq[t][kc], acc);
+                const int mq = (int)m0 + t * 16 + l15, bq_ = mq / p.Tp;
+                if (mq < p.M) {
+                    T* dst = (sg == 0 ? Qo : Ko) + ((long)bq_ * p.heads * p.Tp + (mq - bq_ * p.Tp)) * p.hd + (long)hh * p.Tp * p.hd + dd;
+                    *(V4*)dst = cvt4<T>(acc * (sg == 0 ? p.qscale : 1.f));
+                }
+            } else {
+                const int nl = nl0 + l15, hh = nl / p.hd, dd = nl - hh * p.hd;
+                const float bb = bqs[2 * C + nl];
+                f32x4 acc = {bb, bb, bb, bb};
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(xq[t][kc], wq[kc], acc);
+                const int mv = (int)m0 + t * 16 + g * 4, bv_ = mv / p.Tp;
+                if (mv < p.M)
+                    *(V4*)(Vo + (long)bv_ * p.heads * p.hd * p.Tp + (mv - bv_ * p.Tp) + ((long)hh * p.hd + dd) * p.Tp) = cvt4<T>(acc);
+            }
+        }
+    }
+}
+
+template <typename T, bool QKV>
+int launch_mlp_small(const MlpParams& p, hipStream_t st) {
+    constexpr int C = 192;
+    constexpr size_t lds = 32 * (C + 8) * sizeof(T) + (size_t)NW * 6 * 2 * 256 * sizeof(float) + 11 * C * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)mlp_small_kernel<T, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const long blocks = (p.M + 31) / 32;
+    ProfScope ps(KID_MLP, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C, (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T), st);
+    hipLaunchKernelGGL((mlp_small_kernel<T, QKV>), dim3((unsigned)blocks), dim3(NTHR), lds, st, p);
+    return lwdetr_check_launch();
+}
+
 template <typename T, int C, int TT, bool PROJ, bool QKV>
 int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -526,8 +779,15 @@ int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     return lwdetr_check_launch();
 }
 
+constexpr long MLP_SMALL_MAX_ROWS = 12800;       // below ~8 images the tile-per-workgroup kernel wins (see mlp_small_kernel)
+
 template <typename T, int C, int TT>
 int launch_mlp(const MlpParams& p, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && C == 192) {
+        static const char* env = getenv("LWDETR_MLP_SMALL");       // tuning: 0 = never, 1 = always
+        const bool small_ok = p.att && (env ? atoi(env) == 1 : p.M < MLP_SMALL_MAX_ROWS);
+        if (small_ok) return p.wqkv ? launch_mlp_small<T, true>(p, st) : launch_mlp_small<T, false>(p, st);
+    }
     if (p.att && p.wqkv) return launch_mlp_p<T, C, TT, true, true>(p, st);
     if (p.att) return launch_mlp_p<T, C, TT, true, false>(p, st);
     if (p.wqkv) return LWDETR_ERR_UNSUPPORTED;          // the chained QKV is only built together with the projection

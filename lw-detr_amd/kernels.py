@@ -129,13 +129,16 @@ def mlp_fused_supported(C_, dtype, rows=None) -> bool:
     With ``rows`` given this is the launch-plan choice: the fused kernel gives every wave ONE 32-token tile and walks all
     hidden chunks with it, so its run time is flat (~70-100 us) up to 65k tokens; for a few images the 6 separate launches
     (LN, QKV, proj, LN, fc1+GELU, fc2) spread the same work over all CUs and win (bs=1 latency). LWDETR_MLP_FUSED=0/1
-    forces either."""
+    forces either. (16-bit C = 192 is always fused: for a few images the C entry point uses a second kernel that makes one
+    32-token tile a workgroup and splits the hidden dimension over its waves.)"""
     ok = C_ == 192 or (C_ == 384 and dtype in (torch.float16, torch.bfloat16))
     if not ok or rows is None:
         return ok
     force = os.environ.get("LWDETR_MLP_FUSED")
     if force in ("0", "1"):
         return force == "1"
+    if C_ == 192 and dtype in (torch.float16, torch.bfloat16):
+        return True             # lwdetr_mlp_fused switches to its tile-per-workgroup kernel below MLP_FUSED_MIN_ROWS by itself
     return rows >= MLP_FUSED_MIN_ROWS
 
 
