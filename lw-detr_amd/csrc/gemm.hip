@@ -198,7 +198,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const lwdetr_gemm_desc d) {
     constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
     constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
     typedef typename Vec<T>::v8 V8;
-    typedef typename Vec<T>::v4 V4;
 
     __shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LDS_LD];
 
