@@ -279,6 +279,372 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     }
 }
 
+
+// =====================================================================================================================
+// Long-sequence variant (global attention of the ViT: 1600 / 3600 keys, 16-bit types). Same math as attn_kernel, built
+// around the 32x32x16 MFMA and an LDS ring that the waves of a workgroup share:
+//   * a workgroup = NW waves x 32*QT queries of ONE (image, head); K and V^T stream through an NST-deep ring of 64-key
+//     stages, filled by global_load_lds DMA in whole 128-byte lines (1 KB pieces), counted s_waitcnt vmcnt + one raw
+//     s_barrier per stage. K / V^T enter a CU once per workgroup instead of once per wave, and workgroups of one
+//     (image, head) run back to back on one XCD (bijective blockIdx remap) so its L2 serves the re-reads.
+//   * scores: S^T = K Q^T as ONE 32x32x16 MFMA per 16 channels (hd = 16: a single instruction per 32 keys x 32 queries,
+//     where the 16x16x16 form ran the matrix pipe at half rate). The K rows of a 32-key group enter the A operand with
+//     key bits 2 and 3 swapped, which makes the 16 scores a lane owns (query = lane & 31) two runs of 8 CONSECUTIVE keys:
+//     registers 8s..8s+7 <-> keys 16s + 8*(lane >> 5) + 0..7. That is exactly the B-operand layout of O^T = V^T P^T with
+//     the 32x32x16 MFMA (k-slots 8*(lane >> 5) + e of 16-key slice s): P goes from accumulator to operand with a
+//     conversion only - no LDS, no cross-lane moves - and the V^T operand is one 16-byte LDS read per lane.
+//   * hd = 16 fills only 16 of the 32 output rows of the P V MFMA: row 16 of the V^T image is all ones (rows 17-31 zero,
+//     written once, never touched by the DMA), so the softmax denominator drops out of the same instruction.
+//     hd >= 32: denominators by v_dot2c on the packed P (the values the MFMA consumes).
+//   * LDS images are row-major with an XOR swizzle of the 16-byte slots (slot ^= (row / rows_per_256B) & (slots - 1)):
+//     conflict-free for the 16-lane service groups of ds_read_b128; a DMA piece is lane-linear in LDS, so the swizzle is
+//     applied to the SOURCE address (cdna guide rule 21).
+// The DMA is issued through inline assembly: hipcc does not count it, so its own waits (for the Q loads, consumed once
+// before the loop) never drain the ring; the ring is ordered by the hand-placed counted waits only.
+template <typename T> struct Mma32;
+template <> struct Mma32<f16> {
+    static __device__ __forceinline__ f32x16 k16(f16x8 a, f16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float dot2(f16x8 p, int i, float c) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 a = {p[2 * i], p[2 * i + 1]}, one = {(f16)1.f, (f16)1.f};
+        return __builtin_amdgcn_fdot2(a, one, c, false);
+    }
+};
+template <> struct Mma32<bf16> {
+    static __device__ __forceinline__ f32x16 k16(bf16x8 a, bf16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float dot2(bf16x8 p, int i, float c) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        const b2 a = {p[2 * i], p[2 * i + 1]}, one = {(bf16)1.f, (bf16)1.f};
+        return __builtin_amdgcn_fdot2_f32_bf16(a, one, c, false);
+    }
+};
+
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4];     // source of dummy DMA pieces
+
+// one 1 KB DMA piece: 64 lanes x 16 bytes, LDS destination = wave-uniform base + 16 * lane (m0 written in the statement)
+__device__ __forceinline__ void attn_dma16(const void* src, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_base), "v"(src) : "memory");
+}
+template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int HD, int QT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_desc p) {
+    typedef typename Vec<T>::v8 V8;
+    constexpr int NC = HD / 16;                        // 16-deep contraction chunks of K Q^T
+    constexpr int RT = HD > 32 ? HD / 32 : 1;          // 32-row tiles of O^T
+    constexpr int RB = HD * 2;                         // bytes of a K row
+    constexpr int CPR = RB / 16, RPB = 256 / RB;       // 16-byte slots per K row, K rows per 256 bytes
+    constexpr int KB = 64;                             // keys per stage (one 128-byte line of every V^T row)
+    constexpr int KIMG = KB * RB, VIMG = RT * 32 * 128, STAGE = KIMG + VIMG;
+    constexpr int NKP = KIMG / 1024, NVP = HD * 128 / 1024, NP = NKP + NVP;   // DMA pieces per stage (real V^T rows only)
+    constexpr int PPW = (NP + NW - 1) / NW;            // ... per wave (the same for every wave: dummies fill up)
+    constexpr int NST = 3;
+    constexpr int QW = 32 * QT, QWG = QW * NW;
+    constexpr float RESCALE_THR = 8.f;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 1024];     // ring + landing area of dummy pieces
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int nkeys = p.keys_per_seq;
+    const int wgs_per_seq = (nkeys + QWG - 1) / QWG;
+    int wid;
+    {   // workgroups of one (image, head) - and of one image - run on the same XCD, next to each other in time
+        const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int qblk = wid % wgs_per_seq;
+    const int rest = wid / wgs_per_seq;
+    const int head = rest % p.heads, seq = rest / p.heads;
+    const int b = seq / p.seqs_per_img, w = seq - b * p.seqs_per_img;
+    const long tok0 = (long)w * p.seq_tok_stride;
+    const long bh = (long)b * p.heads + head;
+    const T* __restrict__ Qb = (const T*)p.Q + (bh * p.Tp + tok0) * HD;
+    const T* __restrict__ Kb = (const T*)p.K + (bh * p.Tp + tok0) * HD;
+    const T* __restrict__ Vb = (const T*)p.VT + bh * HD * (long)p.Tp + tok0;
+    const int q0 = qblk * QWG + wave * QW;
+    const bool active = q0 < nkeys;                    // wave-uniform; idle waves still feed the ring and hit the barriers
+    const int nblk = nkeys / KB;                       // launcher guarantees nkeys % 64 == 0
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = m][16c + 8h .. + 7]
+    V8 qf[QT][NC];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int q = q0 + t * 32 + m; q = q < nkeys ? q : nkeys - 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qf[t][c] = *(const V8*)(Qb + (long)q * HD + c * 16 + h * 8);
+    }
+
+    // ---- DMA piece table of this wave: piece i = wave + j * NW of a stage (K pieces first, then V^T, then dummies)
+    const T* src0[PPW]; int sstep[PPW]; unsigned dst0[PPW]; bool real[PPW];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    const unsigned dummy_dst = lds0 + NST * STAGE;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int i = wave + j * NW;
+        if (i < NKP) {
+            const int off = i * 1024 + lane * 16;                       // byte offset inside the K image
+            const int key = off / RB, slot = (off % RB) / 16;
+            const int chunk = slot ^ ((key / RPB) & (CPR - 1));
+            src0[j] = Kb + key * HD + chunk * 8; sstep[j] = KB * HD; dst0[j] = i * 1024; real[j] = true;
+        } else if (i < NP) {
+            const int v = i - NKP;
+            const int row = 8 * v + (lane >> 3), slot = lane & 7;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            src0[j] = Vb + (long)row * p.Tp + chunk * 8; sstep[j] = KB; dst0[j] = KIMG + v * 1024; real[j] = true;
+        } else {
+            src0[j] = (const T*)g_attn_zero16; sstep[j] = 0; dst0[j] = 0; real[j] = false;
+        }
+    }
+    auto issue = [&](int blk, int slot_) {             // always PPW pieces per wave: the wait counts are constants
+        const unsigned sb = lds0 + slot_ * STAGE;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const bool live = real[j] && blk < nblk;    // wave-uniform
+            const T* src = live ? src0[j] + (long)blk * sstep[j] : (const T*)g_attn_zero16;
+            attn_dma16(src, __builtin_amdgcn_readfirstlane(live ? sb + dst0[j] : dummy_dst));
+        }
+    };
+
+    // ---- constant rows of the V^T images (hd = 16): row 16 = ones (the denominator), rows 17..31 = zero
+    if (HD == 16) {
+        V8 one8, zero8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { one8[e] = from_f32<T>(1.f); zero8[e] = from_f32<T>(0.f); }
+        for (int i = threadIdx.x; i < NST * 16 * 8; i += NW * 64) {       // 16 rows x 8 slots per stage
+            const int st = i / 128, r = (i % 128) / 8, sl = i % 8;
+            *(V8*)(smem + st * STAGE + KIMG + (16 + r) * 128 + sl * 16) = r == 0 ? one8 : zero8;
+        }
+    }
+
+    // ---- per-lane LDS read offsets. K: key pi(m) = m with bits 2 and 3 swapped; V^T: row = m (+ 32 rt)
+    const int km = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
+    int kofs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kofs[c] = km * RB + (((2 * c + h) ^ ((km / RPB) & (CPR - 1))) << 4);
+    int vofs[2][2];                                    // [32-key group][16-key slice]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) vofs[t][s] = KIMG + m * 128 + (((4 * t + 2 * s + h) ^ ((m >> 1) & 7)) << 4);
+
+    // ---- accumulators. negm = -reference of the lane's query, replicated: the C operand of the score MFMA
+    f32x16 o[QT][RT], negm[QT];
+    float lsum[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        lsum[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[t][e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t][r][e] = 0.f;
+    }
+    const bool holes = p.sub_len < p.sub_stride;
+    int res0 = 0;                                      // (first key of the current 32-key group) mod sub_stride
+
+    // ---- ring prologue, then make sure Q is in registers before the loop (see the header: the compiler's wait for these
+    // loads must not end up inside the loop, where it would drain the ring every iteration)
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s, s);
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) asm volatile("" :: "v"(qf[t][c]));
+
+    int slot = 0;
+    for (int kb = 0; kb < nblk; ++kb) {
+        attn_wait_vmcnt<(NST - 2) * PPW>();            // stage kb has landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody has also left stage kb - 1
+        {
+            int ns = slot + NST - 1; ns = ns >= NST ? ns - NST : ns;
+            issue(kb + NST - 1, ns);                   // refill the buffer stage kb - 1 used
+        }
+        const char* sK = smem + slot * STAGE;
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                V8 kf[NC], vf[2][RT];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) kf[c] = *(const V8*)(sK + t * 32 * RB + kofs[c]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) vf[s][r] = *(const V8*)(sK + r * 4096 + vofs[t][s]);
+                f32x16 sc[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    f32x16 a = negm[qt];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) a = Mma32<T>::k16(kf[c], qf[qt][c], a);
+                    sc[qt] = a;
+                }
+                // pad rows inside the sequence (960 x 960: 225 tokens in 228-row windows): register e <-> key
+                // k0 + 16 (e >> 3) + 8 h + (e & 7)
+                if (holes && res0 + 31 >= p.sub_len) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        int rr = res0 + 16 * (e >> 3) + 8 * h + (e & 7);
+                        rr = rr >= p.sub_stride ? rr - p.sub_stride : rr;
+                        const bool ok = rr < p.sub_len;
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) sc[qt][e] = ok ? sc[qt][e] : -INFINITY;
+                    }
+                }
+                res0 += 32; res0 = res0 >= p.sub_stride ? res0 - p.sub_stride : res0;
+                // lazy rescale: the reference only moves when a score exceeds it by 2^RESCALE_THR (always on the first group)
+                float lmax[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float lm = max3(sc[qt][0], sc[qt][1], sc[qt][2]);
+#pragma unroll
+                    for (int e = 3; e < 15; e += 2) lm = max3(lm, sc[qt][e], sc[qt][e + 1]);
+                    lmax[qt] = __builtin_fmaxf(lm, sc[qt][15]);
+                }
+                float lall = lmax[0];
+#pragma unroll
+                for (int qt = 1; qt < QT; ++qt) lall = __builtin_fmaxf(lall, lmax[qt]);
+                const bool first = kb == 0 && t == 0;
+                if (__any(first || lall > RESCALE_THR)) {
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        float mx = xor32_max(lmax[qt]);                 // both halves of the query's 32 keys
+                        mx = first ? mx : fmaxf(mx, 0.f);               // the reference never decreases
+                        const float alpha = __builtin_amdgcn_exp2f(-mx);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { negm[qt][e] -= mx; sc[qt][e] -= mx; }
+                        lsum[qt] *= alpha;
+#pragma unroll
+                        for (int r = 0; r < RT; ++r)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) o[qt][r][e] *= alpha;
+                    }
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    V8 pf[2];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pf[e >> 3][e & 7] = from_f32<T>(__builtin_amdgcn_exp2f(sc[qt][e]));
+                    if (HD > 16) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lsum[qt] = Mma32<T>::dot2(pf[s], i, lsum[qt]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) o[qt][r] = Mma32<T>::k16(vf[s][r], pf[s], o[qt][r]);
+                }
+            }
+        } else {
+            res0 += 64; res0 %= p.sub_stride;
+        }
+    }
+    attn_wait_vmcnt<0>();                              // the dummy tail pieces
+    if (!active) return;
+
+    // ---- normalise and store. O^T register e of tile r <-> channel 32 r + 8 (e >> 2) + 4 h + (e & 3) of query m; a
+    // permlane32 swap pairs the halves so that every lane stores 16 contiguous bytes (channels 32 r + 16 j + 8 h .. + 7)
+    T* __restrict__ out = (T*)p.out;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l;
+        if (HD == 16) {
+            const unsigned x = __float_as_uint(o[qt][0][8]);            // row 16 (lanes h = 0): sum of P
+            const auto rr = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+            l = __uint_as_float(rr[0]);
+        } else {
+            l = xor32_sum(lsum[qt]);
+        }
+        const float inv = 1.f / l;
+        const int q = q0 + qt * 32 + m;
+        T* orow = out + ((long)b * p.Tp + tok0 + q) * p.ldo + head * HD;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int j = 0; j < (HD == 16 ? 1 : 2); ++j) {
+                typedef typename Vec<T>::v4 V4;
+                V4 a4, b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a4[e] = from_f32<T>(o[qt][r][8 * j + e] * inv);
+                    b4[e] = from_f32<T>(o[qt][r][8 * j + 4 + e] * inv);
+                }
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                u2 au = __builtin_bit_cast(u2, a4), bu = __builtin_bit_cast(u2, b4);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(au[d], bu[d], false, false);
+                    au[d] = sw[0]; bu[d] = sw[1];
+                }
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                const u4 st = {au[0], au[1], bu[0], bu[1]};
+                if (q < nkeys) *(u4*)(orow + r * 32 + j * 16 + h * 8) = st;
+            }
+    }
+}
+
+template <typename T, int HD, int QT, int NW>
+int launch_lds(const lwdetr_attn_desc& p, hipStream_t st) {
+    const int wgs_per_seq = (p.keys_per_seq + 32 * QT * NW - 1) / (32 * QT * NW);
+    const long nwg = (long)wgs_per_seq * p.heads * p.B * p.seqs_per_img;
+    const double nseq = (double)p.B * p.seqs_per_img;
+    const double flops = 4.0 * nseq * p.heads * (double)p.keys_per_seq * p.keys_per_seq * HD;
+    const double bytes = 4.0 * nseq * p.heads * p.keys_per_seq * HD * sizeof(T);
+    ProfScope ps(p.kind == 0 ? KID_ATTN_WINDOW : (p.kind == 1 ? KID_ATTN_GLOBAL : KID_ATTN_DECODER), flops, bytes, st);
+    hipLaunchKernelGGL((attn_lds_kernel<T, HD, QT, NW>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
+    return lwdetr_check_launch();
+}
+
+// The LDS-ring kernel serves long, 64-aligned sequences of the 16-bit types; everything else (windows, the decoder's 300
+// queries, f32 parity mode) stays on attn_kernel. LWDETR_ATTN_LDS=0 forces attn_kernel, LWDETR_ATTN_LDS_CFG=<100 QT + NW>
+// (108, 110, 204, 205, 208) picks a tuning variant.
+// Measured on MI355X (tools/attn_bench.py, us per launch, attn_kernel | 2x5 | 2x4 | 1x8 | 2x8):
+//   small  B32 f16  hd16 1600 keys:  191 | 238 | 201 | 181 | 199        medium B64 bf16 hd32: 475 | 599 | 493 | 446 | 506
+//   large  B32 f16  hd32 1600 keys:  261 | 312 | 269 | 235 | 252        xlarge B16 f16 hd64 3648 keys: 2226 | 1068 | 895 | 848 | 827
+// hd <= 32 is bound by the exponentials (v_exp_f32 issues at 8.5 cycles per wave and does NOT overlap other VALU work on
+// this chip, tools/ubench/overlap.hip): 32 queries per wave keep the register count at 84-92 (5 waves per SIMD), which is
+// what hides the LDS / barrier latencies there; hd = 64 is matrix-bound and prefers the K / V^T reuse of 64 queries per wave.
+template <typename T, int HD>
+int launch_lds_cfg(const lwdetr_attn_desc& p, hipStream_t st) {
+    static const char* cfg = getenv("LWDETR_ATTN_LDS_CFG");
+    int c = cfg ? atoi(cfg) : 0;
+    if (!c) c = HD >= 64 ? 208 : 108;
+    switch (c) {
+        case 108: return launch_lds<T, HD, 1, 8>(p, st);
+        case 110: return launch_lds<T, HD, 1, 10>(p, st);
+        case 204: return launch_lds<T, HD, 2, 4>(p, st);
+        case 205: return launch_lds<T, HD, 2, 5>(p, st);
+        case 208: return launch_lds<T, HD, 2, 8>(p, st);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}
+template <typename T, int HD> struct LdsPath {
+    static bool ok(const lwdetr_attn_desc&) { return false; }
+    static int go(const lwdetr_attn_desc&, hipStream_t) { return LWDETR_ERR_UNSUPPORTED; }
+};
+template <int HD> struct LdsPath<f16, HD> {
+    static bool ok(const lwdetr_attn_desc& p) { return true; }
+    static int go(const lwdetr_attn_desc& p, hipStream_t st) { return launch_lds_cfg<f16, HD>(p, st); }
+};
+template <int HD> struct LdsPath<bf16, HD> {
+    static bool ok(const lwdetr_attn_desc& p) { return true; }
+    static int go(const lwdetr_attn_desc& p, hipStream_t st) { return launch_lds_cfg<bf16, HD>(p, st); }
+};
+static bool lds_path_applies(const lwdetr_attn_desc& p) {
+    static const char* force = getenv("LWDETR_ATTN_LDS");
+    if (force && atoi(force) == 0) return false;
+    return p.keys_per_seq >= 512 && p.keys_per_seq % 64 == 0 && p.seq_tok_stride % 8 == 0 && p.Tp % 8 == 0 &&
+           p.ldo % 8 == 0 && (p.sub_len == p.sub_stride || p.sub_stride >= 64);
+}
+
 template <typename T, int HD, int QT>
 int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
     const int units = (p.keys_per_seq + 16 * QT - 1) / (16 * QT);
@@ -294,6 +660,7 @@ int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
 
 template <typename T, int HD>
 int launch(const lwdetr_attn_desc& p, hipStream_t st) {
+    if (LdsPath<T, HD>::ok(p) && lds_path_applies(p)) return LdsPath<T, HD>::go(p, st);
     // long sequences: 64 queries per wave (K / V^T fragments amortised over 4 query tiles); short ones keep 32 so a
     // 100-token window still spreads over 4 waves
     static const char* force = getenv("LWDETR_ATTN_QT");

@@ -7,14 +7,16 @@ pickle -> ByteTensor -> padded ``all_gather`` -> unpickle of per-image results (
 (score, label, x0, y0, x1, y1; labels < 2^24 are exact in f32). No other collective is on the data path.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, single_node=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank); a no-op returning (0, 1, 0) when WORLD_SIZE is absent or 1."""
+    Returns (rank, world_size, local_rank); a no-op returning (0, 1, 0) when WORLD_SIZE is absent or 1.
+    ``single_node`` (default: inferred from LOCAL_WORLD_SIZE == WORLD_SIZE) gates the loopback-only RCCL bootstrap."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1, 0
@@ -24,9 +26,16 @@ def init_from_env(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
     if backend == "nccl":
-        # single node, xGMI only: no InfiniBand / socket transport for data
-        os.environ.setdefault("NCCL_IB_DISABLE", "1")
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        if single_node is None:     # torchrun exports LOCAL_WORLD_SIZE: all ranks on this node <=> it equals WORLD_SIZE
+            single_node = int(os.environ.get("LOCAL_WORLD_SIZE", "0")) == world
+        if single_node:
+            # one node, xGMI only: keep RCCL's bootstrap on loopback and off InfiniBand. Only applied when the job is
+            # known to be single-node (on a multi-node job these would force a loopback bootstrap and hang), and never
+            # over a value the caller has set.
+            for k, v in (("NCCL_IB_DISABLE", "1"), ("NCCL_SOCKET_IFNAME", "lo")):
+                if k not in os.environ:
+                    os.environ[k] = v
+                    print(f"[lwdetr_amd.dist] single-node job: {k}={v}", file=sys.stderr, flush=True)
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -163,11 +163,15 @@ def _attn_ref(q, k, v, valid):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("hd", [16, 32, 64])
-@pytest.mark.parametrize("geom", ["window100", "global1600", "holes", "decoder300"])
+@pytest.mark.parametrize("geom", ["window100", "global1600", "holes", "decoder300", "holes3648", "global704"])
 def test_attention(dtype, hd, geom):
     from lwdetr_amd import kernels as K
     heads, b = 3, 2
-    if geom == "window100":
+    if geom == "holes3648":        # the real 960x960 geometry (LDS-ring kernel for the 16-bit types): 225 tokens in 228 rows
+        twp, tw, spi, b, heads = 228, 225, 1, 1, 2
+    elif geom == "global704":      # 11 x 64 keys: partially filled last workgroup of the LDS-ring kernel
+        twp, tw, spi = 44, 44, 1
+    elif geom == "window100":
         twp, tw, spi = 100, 100, 16
     elif geom == "global1600":
         twp, tw, spi = 100, 100, 1
@@ -181,6 +185,7 @@ def test_attention(dtype, hd, geom):
     v = _rand(b, heads, tp, hd, dtype=dtype, seed=3)
     # spike one key against one query so the online-softmax rescale branch is exercised late in the sequence
     k[0, 0, tp - 3] = q[0, 0, 5] * 4
+    k[0, 1, tp // 2 + 1] = q[0, 1, 40] * 4
     scale = K.attention_scale(hd)
     qs = (q.float() * scale).to(dtype)
     out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())

@@ -1,0 +1,64 @@
+"""Times the global-attention launch shapes of the BASELINE configs with the attn_kernel / LDS-ring variants
+(LWDETR_ATTN_LDS, LWDETR_ATTN_LDS_CFG are read once per process, so every variant runs in a child process).
+
+    python tools/attn_bench.py            # all shapes x all variants
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SHAPES = {  # name: (B, heads, hd, twp, tw, dtype)
+    "small_b32_f16": (32, 12, 16, 100, 100, "float16"),
+    "medium_b64_bf16": (64, 12, 32, 100, 100, "bfloat16"),
+    "large_b32_f16": (32, 12, 32, 100, 100, "float16"),
+    "xlarge960_b16_f16": (16, 12, 64, 228, 225, "float16"),
+    "small_b1_f16": (1, 12, 16, 100, 100, "float16"),
+}
+VARIANTS = [("attn_kernel", {"LWDETR_ATTN_LDS": "0"}), ("lds 1x8", {"LWDETR_ATTN_LDS_CFG": "108"}),
+            ("lds 1x10", {"LWDETR_ATTN_LDS_CFG": "110"}), ("lds 2x4", {"LWDETR_ATTN_LDS_CFG": "204"}),
+            ("lds 2x5", {"LWDETR_ATTN_LDS_CFG": "205"}), ("lds 2x8", {"LWDETR_ATTN_LDS_CFG": "208"})]
+
+
+def child(shape):
+    import torch
+    from lwdetr_amd import kernels as K
+    B, heads, hd, twp, tw, dt = SHAPES[shape]
+    T = getattr(torch, dt)
+    dev, Tp = "cuda:0", 16 * twp
+    g = torch.Generator(device="cpu").manual_seed(0)
+    q = (torch.randn(B, heads, Tp, hd, generator=g) * 0.5).to(dev).to(T)
+    k = torch.randn(B, heads, Tp, hd, generator=g).to(dev).to(T)
+    vt = torch.randn(B, heads, hd, Tp, generator=g).to(dev).to(T)
+    out = torch.zeros(B * Tp, heads * hd, device=dev, dtype=T)
+    op = K.AttnOp(q, k, vt, out, B=B, heads=heads, hd=hd, Tp=Tp, ldo=heads * hd, seqs_per_img=1, seq_tok_stride=Tp,
+                  keys_per_seq=Tp, sub_stride=twp, sub_len=tw, kind=1)
+    for _ in range(3):
+        op()
+    ts = []
+    for _ in range(15):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); op(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    flops = 4.0 * B * heads * Tp * Tp * hd
+    med = ts[len(ts) // 2]
+    print(f"{med:9.1f} us (min {ts[0]:.1f})  {flops / med / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--child":
+        return child(sys.argv[2])
+    only = sys.argv[1:] or list(SHAPES)
+    for shape in only:
+        for name, env in VARIANTS:
+            e = dict(os.environ, **env)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", shape], env=e, capture_output=True,
+                               text=True, timeout=300)
+            res = r.stdout.strip().splitlines()[-1] if r.returncode == 0 and r.stdout.strip() else f"FAILED rc={r.returncode} {r.stderr[-300:]}"
+            print(f"{shape:20s} {name:12s} {res}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
