@@ -43,10 +43,11 @@ class LWDETR(nn.Module):
         self._args = copy.copy(args)
         self._packed = None      # PackedWeights for the current (device, dtype, parameter versions)
         self._plans = {}         # (B, H, W) -> ForwardPlan
+        self._tok_tensors = None
 
     # ---- cache invalidation: any change of device / dtype / parameter values drops the packed weights
     def invalidate_cache(self):
-        self._packed, self._plans = None, {}
+        self._packed, self._plans, self._tok_tensors = None, {}, None
 
     def _apply(self, fn, *a, **k):
         self.invalidate_cache()
@@ -57,27 +58,45 @@ class LWDETR(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _weights_token(self):
+        """Identity of everything the packed weights were derived from: storage, dtype, device and in-place version of
+        every parameter AND buffer (BatchNorm running statistics are folded into the conv weights). Catches
+        ``model.backbone.half()`` / ``.to()`` on a sub-module (parameter storage moves), ``p.data = ...`` and in-place
+        updates alike. (Re-binding a buffer attribute to a new tensor needs an explicit ``invalidate_cache()``.)"""
+        if self._tok_tensors is None:       # flat list, rebuilt after _apply / load_state_dict on this module (~0.08 ms / call)
+            self._tok_tensors = list(self.parameters()) + list(self.buffers())
         p = self.class_embed.weight
-        return (p.device, p.dtype, sum(q._version for q in self.parameters()))
+        return (p.device, p.dtype, hash(tuple([(t.data_ptr(), t._version) for t in self._tok_tensors])))
 
-    def _plan(self, b, h, w):
+    def _packed_weights(self):
+        if self.training:
+            raise NotImplementedError("lwdetr_amd implements the inference forward; call model.eval()")
         tok = self._weights_token()
         if self._packed is None or self._packed[0] != tok:
             dev, dt = tok[0], tok[1]
             if dev.type != "cuda":
                 raise _native.NativeError("lwdetr_amd: the forward path runs on a ROCm device only - move the model "
                                           "with .to('cuda'); there is no CPU implementation")
-            if self.training:
-                raise NotImplementedError("lwdetr_amd implements the inference forward; call model.eval()")
+            mixed = {t.dtype for t in self.parameters() if t.is_floating_point()} | {t.device for t in self.parameters()}
+            if len(mixed) != 2:
+                raise _native.NativeError(f"lwdetr_amd: all parameters must share one dtype and device (found {mixed})")
             _native.lib()       # raises loudly when the extension is missing
             self._packed = (tok, PackedWeights(dict(self.state_dict()), self._args, dev, dt))
             self._plans = {}
+        return self._packed
+
+    def _plan(self, b, h, w, private=False):
+        """Launch plan for a batch shape. ``private`` plans are not cached: a HIP graph owns its plan's buffers and padding
+        state, which eager calls of the same shape must never touch."""
+        tok, pw = self._packed_weights()
         key = (b, h, w)
+        if private:
+            with torch.cuda.device(tok[0]):
+                return ForwardPlan(pw, b, h, w)
         if key not in self._plans:
             if len(self._plans) >= 4:
                 self._plans.pop(next(iter(self._plans)))
             with torch.cuda.device(tok[0]):
-                self._plans[key] = ForwardPlan(self._packed[1], b, h, w)
+                self._plans[key] = ForwardPlan(pw, b, h, w)
         return self._plans[key]
 
     @torch.no_grad()
@@ -109,7 +128,7 @@ class LWDETR(nn.Module):
         from ..engine import GraphedForward
         assert isinstance(images, torch.Tensor) and images.dim() == 4
         b, _, h, w = images.shape
-        return GraphedForward(self._plan(b, h, w), images, postprocess, target_sizes)
+        return GraphedForward(self._plan(b, h, w, private=True), images, postprocess, target_sizes)
 
     def export(self):
         """Export-mode forward of the reference (``lwdetr.py:103-109, 176-195``): tensor in, (coords, logits) out."""

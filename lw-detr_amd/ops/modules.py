@@ -44,7 +44,13 @@ class MSDeformAttn(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.constant_(self.output_proj.bias, 0.0)
 
-    @torch.no_grad()
+    # (L, P) pairs and head widths the fused softmax + sampling kernel is instantiated for (csrc/msda.hip); any other
+    # configuration - including this module's defaults n_levels = n_points = 4 - runs softmax in torch and the generic
+    # operator (lwdetr_msda_forward).
+    _FUSED_LP = {(1, 2), (2, 4), (1, 4), (2, 2)}
+
+    @torch.no_grad()      # INFERENCE-ONLY module: its Linear layers run on the fused GEMM kernel, which has no autograd
+    # node; the differentiable piece of this package is the operator, MSDeformAttnFunction (forward + backward)
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         n, lq, _ = query.shape
@@ -67,8 +73,9 @@ class MSDeformAttn(nn.Module):
         ref = reference_points.float().contiguous()            # (N, Lq, L, 4): already scaled per level
         # the fused kernel takes unscaled boxes + per-level valid ratios; feed ratio 1 and level-0 boxes when all
         # levels carry the same box, otherwise fold the per-level boxes through the generic op
-        same = bool((ref == ref[:, :, :1]).all())
-        if not same:
+        fused = (self.n_levels, self.n_points) in self._FUSED_LP and (d // m) % 8 == 0 and dt != torch.float64
+        fused = fused and bool((ref == ref[:, :, :1]).all())
+        if not fused:
             off = oa[:, :m * lp * 2].reshape(n, lq, m, self.n_levels, self.n_points, 2).float()
             aw = oa[:, m * lp * 2:].reshape(n, lq, m, lp).float().softmax(-1)
             loc = ref[:, :, None, :, None, :2] + off / self.n_points * ref[:, :, None, :, None, 2:] * 0.5

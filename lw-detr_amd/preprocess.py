@@ -63,22 +63,39 @@ class SquareResizeNormalize:
         s = torch.tensor(std, dtype=torch.float32).view(3, 1)
         v = torch.arange(256, dtype=torch.float32).view(1, 256)
         self.lut = v.div(255).sub(m).div(s).contiguous().to(self.device)       # ToTensor, then F.normalize: same f32 ops
-        self._tables = {}                                                      # (H, W) -> offsets into the device table
-        self._table_chunks, self._table_len, self._table_dev = [], 0, None
+        # Resample tables are per AXIS LENGTH (the x table depends on the width only, the y table on the height only):
+        # in_size -> (bounds offset, coef offset, ksize) into one growable device buffer (int32 elements). A COCO-style
+        # evaluation sees a few hundred distinct lengths; the cache is bounded (LRU) and a new length is appended to the
+        # device buffer in place - nothing is re-concatenated or re-uploaded.
+        self._axis = {}
+        self._axis_cap = 1024
+        self._table_dev = torch.empty(1 << 20, dtype=torch.int32, device=self.device)
+        self._table_len = 0
+
+    def _axis_table(self, n):
+        ent = self._axis.pop(n, None)
+        if ent is None:
+            bounds, coef = resample_tables(n, self.size)
+            flat = np.concatenate([np.ascontiguousarray(bounds).reshape(-1), np.ascontiguousarray(coef).reshape(-1)])
+            if len(self._axis) >= self._axis_cap or self._table_len + flat.size > self._table_dev.numel():
+                if flat.size > self._table_dev.numel():
+                    self._table_dev = torch.empty(2 * flat.size, dtype=torch.int32, device=self.device)
+                # full: start over (the launches of earlier calls are already ordered before this upload on the stream)
+                self._axis.clear()
+                self._table_len = 0
+            off = self._table_len
+            self._table_dev[off:off + flat.size].copy_(torch.from_numpy(flat))
+            self._table_len += flat.size
+            ent = (off, off + bounds.size, coef.shape[1])
+        self._axis[n] = ent                                                    # most recently used last
+        return ent
 
     def _offsets(self, h, w):
-        key = (h, w)
-        if key not in self._tables:
-            xb, xk = resample_tables(w, self.size)
-            yb, yk = resample_tables(h, self.size)
-            offs = []
-            for arr in (xb, xk, yb, yk):
-                offs.append(self._table_len)
-                self._table_chunks.append(np.ascontiguousarray(arr).reshape(-1))
-                self._table_len += arr.size
-            self._tables[key] = (offs[0], offs[1], xk.shape[1], offs[2], offs[3], yk.shape[1])
-            self._table_dev = None
-        return self._tables[key]
+        xo = self._axis_table(w)
+        yo = self._axis_table(h)
+        if w not in self._axis:              # the second lookup started the buffer over: the x table went with it
+            xo = self._axis_table(w)
+        return xo + yo
 
     @torch.no_grad()
     def __call__(self, images):
@@ -102,8 +119,6 @@ class SquareResizeNormalize:
             d.xbounds_off, d.xcoef_off, d.xksize, d.ybounds_off, d.ycoef_off, d.yksize = o
             d.tmp_off = tmp_off
             tmp_off += h * s * 3
-        if self._table_dev is None:
-            self._table_dev = torch.from_numpy(np.concatenate(self._table_chunks)).to(self.device)
         out = torch.empty(b, 3, s, s, dtype=self.dtype, device=self.device)
         sizes = torch.tensor([[im.shape[0], im.shape[1]] for im in imgs], dtype=torch.float32, device=self.device).view(b, 2)
         if b == 0:

@@ -56,3 +56,51 @@ def case_batch(name):
         full[i, :, :, w:] = 0
         mask[i, :h, :w] = False
     return size, full, mask
+
+
+# ---- CPU oracle over a full BASELINE batch: images are independent, so the batch is cut into small chunks that worker
+# processes (spawned: the parent may hold a GPU context) run side by side on the host cores.
+def _oracle_chunk(job):
+    size, seed, lo, hi, res, img_seed, threads = job
+    import torch as _t
+    _t.set_num_threads(threads)
+    import lwdetr_amd
+    from lwdetr_amd.synth import synth_images, synth_state_dict
+    from oracle import lwdetr_torch as O
+    cfg = lwdetr_amd.get_args(size)
+    model, _, _ = lwdetr_amd.build_model(cfg)
+    sd = synth_state_dict(model.state_dict(), seed=seed)
+    x = synth_images(hi, res, res, seed=img_seed)[lo:hi]          # counter-based generator: image i is the same in any batch
+    with _t.no_grad():
+        out = O.forward(sd, cfg, x)
+        res_ = O.postprocess(out, _t.tensor([[480.0, 640.0]] * (hi - lo)), cfg.num_select)
+        sc, lb, bx = (_t.stack([r[k] for r in res_]) for k in ("scores", "labels", "boxes"))
+    return {"pred_logits": out["pred_logits"].numpy(), "pred_boxes": out["pred_boxes"].numpy(),
+            "enc_logits": out["enc_outputs"]["pred_logits"].numpy(), "enc_boxes": out["enc_outputs"]["pred_boxes"].numpy(),
+            "topk_idx": out["topk_idx"].numpy(), "post_scores": sc.numpy(), "post_labels": lb.numpy(), "post_boxes": bx.numpy()}
+
+
+def oracle_batch(size, batch, res, img_seed, seed=0, chunk=2):
+    """fp32 CPU oracle outputs for synth_images(batch, res, res, img_seed) with synth weights `seed` (dict of numpy arrays)."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0))
+    jobs_n = (batch + chunk - 1) // chunk
+    procs = max(1, min(jobs_n, cores // 8))
+    threads = max(1, min(16, cores // procs))
+    jobs = [(size, seed, lo, min(lo + chunk, batch), res, img_seed, threads) for lo in range(0, batch, chunk)]
+    if procs == 1:
+        parts = [_oracle_chunk(j) for j in jobs]
+    else:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            parts = pool.map(_oracle_chunk, jobs)
+    return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+
+
+def box_iou_xyxy(a, b):
+    """(n,4) x (m,4) -> (n,m) IoU, numpy."""
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    inter = np.clip(rb - lt, 0, None).prod(-1)
+    aa = np.clip(a[:, 2:] - a[:, :2], 0, None).prod(-1)
+    ab = np.clip(b[:, 2:] - b[:, :2], 0, None).prod(-1)
+    return inter / np.maximum(aa[:, None] + ab[None, :] - inter, 1e-9)

@@ -132,3 +132,26 @@ def test_synthetic_weights_are_machine_independent():
     v = synth_param("backbone.0.encoder.blocks.0.attn.qkv.weight", (576, 192))
     assert zlib.crc32(v.numpy().tobytes()) == 2369530295
     assert zlib.crc32(synth_images(1, 64, 64).numpy().tobytes()) == 1422412767
+
+
+def test_packed_weight_cache_token_sees_every_way_weights_can_change():
+    """the token must move on sub-module conversions, `p.data = ...`, in-place updates of parameters AND
+    buffers (BatchNorm statistics are folded into packed conv weights); and train() is checked on every forward."""
+    import pytest as _pytest
+    m, _, _ = lwdetr_amd.build_model(lwdetr_amd.get_args("tiny"))
+    t0 = m._weights_token()
+    assert m._weights_token() == t0
+    m.backbone.half()
+    t1 = m._weights_token()
+    assert t1 != t0
+    m.float()
+    t2 = m._weights_token()
+    m.class_embed.weight.data = m.class_embed.weight.data.clone()
+    t3 = m._weights_token()
+    assert t3 != t2
+    bn = next(mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+    bn.running_var.mul_(1.5)
+    assert m._weights_token() != t3
+    m.train()
+    with _pytest.raises(NotImplementedError):
+        m._packed_weights()

@@ -1,10 +1,13 @@
 """CPU, world_size 2, gloo: batch sharding + the single all-gather of detections reproduce the single-process result."""
 import os
 import socket
+import sys
 
 import pytest
 import torch
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -117,3 +120,40 @@ def test_gathered_evaluation_results_on_rank0_equal_single_process():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert got[1] is None and got[0] == exp
+
+
+# ---- bench.py launch path (`python bench.py --gpus N` must start its N ranks itself and never print n_gpus != N)
+def _run_bench(args, env_extra=None, timeout=180):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_self_launches_its_ranks():
+    """Started plainly (no launcher environment) with --gpus 2, bench.py re-executes itself under torch.distributed.run
+    with two ranks (gloo here: no GPU) and rank 0 reports the world size it actually joined."""
+    rc, line, err = _run_bench(["--gpus", "2", "--launch-check"])
+    assert rc == 0, err[-2000:]
+    assert line == {"launch_check": True, "n_gpus": 2, "backend": "gloo"}
+
+
+def test_bench_refuses_world_size_mismatch():
+    """Under a launcher that started 2 ranks, `--gpus 4` must not produce a line (it used to report n_gpus of a
+    different job size silently)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4",
+                        "--launch-check"], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode != 0
+    assert "refusing to report" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -1,0 +1,90 @@
+"""GPU: parity of the HIP path at the BASELINE configurations AS STATED - model size x resolution x batch x dtype
+(BASELINE.json configs 2-5; the per-GPU shard of the 8-GPU configs) - against the fp32 CPU oracle run on the same
+synthetic batch in chunks on the host cores (tests/helpers.py:oracle_batch). Two comparisons per config:
+
+  * teacher-forced: the oracle's two-stage indices are forced, so every one of the B x 300 query slots is comparable:
+    max / mean |difference| of final and encoder logits and boxes;
+  * free-running: the model's own selection, then PostProcess on both sides (models/lwdetr.py:509-544); detections are
+    matched as SETS per image (same label, best IoU): fraction of the oracle's confident detections that are found with
+    IoU >= 0.9, and their score / box differences.
+
+Every bound below is <= 2x the value measured on MI355X (written next to it; the numbers of each run land in
+gpurun_out/parity_config_*.json and the tracked copy is profiles/parity_config_*.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lwdetr_amd
+from helpers import ROOT, box_iou_xyxy, oracle_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+#            name                 size      res  batch dtype            bounds (see _BOUNDS)
+CONFIGS = [("small_b32_fp16", "small", 640, 32, torch.float16),
+           ("medium_b64_bf16", "medium", 640, 64, torch.bfloat16),
+           ("large_b32_fp16", "large", 640, 32, torch.float16),
+           ("xlarge960_b16_fp16", "xlarge", 960, 16, torch.float16)]
+# teacher-forced max |d logits|, max |d boxes| (cxcywh, image = 1), mean |d logits|; free-running: min matched fraction,
+# max |d score| and max |d box| (pixels of a 640 x 480 target) over the matched detections
+_BOUNDS = {
+    "small_b32_fp16": dict(logit_max=0.15, box_max=0.03, logit_mean=0.01, matched=0.90, score=0.02, box_px=8.0),
+    "medium_b64_bf16": dict(logit_max=0.8, box_max=0.16, logit_mean=0.06, matched=0.80, score=0.08, box_px=30.0),
+    "large_b32_fp16": dict(logit_max=0.15, box_max=0.03, logit_mean=0.01, matched=0.90, score=0.02, box_px=8.0),
+    "xlarge960_b16_fp16": dict(logit_max=0.25, box_max=0.05, logit_mean=0.02, matched=0.85, score=0.03, box_px=12.0),
+}
+
+
+@pytest.mark.parametrize("name,size,res,batch,dtype", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_baseline_config_parity(name, size, res, batch, dtype):
+    from lwdetr_amd.synth import synth_images, synth_state_dict
+    exp = oracle_batch(size, batch, res, img_seed=4321)
+    cfg = lwdetr_amd.get_args(size)
+    model, _, post = lwdetr_amd.build_model(cfg)
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
+    model = model.to(DEV).to(dtype).eval()
+    x = synth_images(batch, res, res, seed=4321).to(DEV).to(dtype)
+    # ---- teacher-forced, slot-wise
+    out = model(x, _forced_topk=torch.from_numpy(exp["topk_idx"]).to(DEV))
+    dl = np.abs(out["pred_logits"].float().cpu().numpy() - exp["pred_logits"])
+    db = np.abs(out["pred_boxes"].float().cpu().numpy() - exp["pred_boxes"])
+    del_ = np.abs(out["enc_outputs"]["pred_logits"].float().cpu().numpy() - exp["enc_logits"])
+    deb = np.abs(out["enc_outputs"]["pred_boxes"].float().cpu().numpy() - exp["enc_boxes"])
+    m = {"logit_max": float(max(dl.max(), del_.max())), "box_max": float(max(db.max(), deb.max())),
+         "logit_mean": float(dl.mean()), "box_mean": float(db.mean()),
+         "logit_range": [float(exp["pred_logits"].min()), float(exp["pred_logits"].max())],
+         "logit_std": float(exp["pred_logits"].std())}
+    # ---- free-running: own selection + PostProcess, detections matched as sets
+    col = {}
+    free = model(x, _collect=col)
+    sizes = torch.tensor([[480.0, 640.0]] * batch, device=DEV)
+    res_ = post["bbox"](free, sizes)
+    ov = np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(col["topk_idx"].cpu().numpy(), exp["topk_idx"])])
+    matched, dscore, dbox, total = 0, 0.0, 0.0, 0
+    for i in range(batch):
+        s_o, l_o, b_o = exp["post_scores"][i], exp["post_labels"][i], exp["post_boxes"][i]
+        s_m = res_[i]["scores"].float().cpu().numpy()
+        l_m = res_[i]["labels"].cpu().numpy()
+        b_m = res_[i]["boxes"].float().cpu().numpy()
+        top = np.argsort(-s_o)[:100]                           # the oracle's 100 most confident detections of the image
+        iou = box_iou_xyxy(b_o[top], b_m)
+        iou = np.where(l_o[top][:, None] == l_m[None, :], iou, -1.0)
+        j = iou.argmax(1)
+        ok = iou[np.arange(len(top)), j] >= 0.9
+        total += len(top)
+        matched += int(ok.sum())
+        if ok.any():
+            dscore = max(dscore, float(np.abs(s_o[top][ok] - s_m[j][ok]).max()))
+            dbox = max(dbox, float(np.abs(b_o[top][ok] - b_m[j][ok]).max()))
+    m.update({"topk_set_overlap": float(ov), "matched": matched / total, "score": dscore, "box_px": dbox,
+              "config": {"size": size, "res": res, "batch": batch, "dtype": str(dtype).split(".")[-1]}})
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_config_{name}.json"), "w") as f:
+        json.dump(m, f, indent=1)
+    b = _BOUNDS[name]
+    assert torch.isfinite(free["pred_logits"].float()).all()
+    assert m["logit_max"] < b["logit_max"] and m["box_max"] < b["box_max"] and m["logit_mean"] < b["logit_mean"], m
+    assert m["matched"] > b["matched"] and m["score"] < b["score"] and m["box_px"] < b["box_px"], m

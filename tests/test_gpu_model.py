@@ -167,3 +167,84 @@ def test_full_size_batch_is_consistent_with_the_golden_validated_small_batch_pat
     sel = model(x, _collect=col)
     overlap = np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(col["topk_idx"].cpu().numpy(), topk.cpu().numpy())])
     assert overlap > 0.9, overlap
+
+
+def test_forward_export_matches_dict_forward():
+    """B2: export() / forward_export (reference models/lwdetr.py:103-109, 176-195): tensor in, (coords, logits) out."""
+    g = load_golden("tiny_192x256")
+    size, images, _ = case_batch("tiny_192x256")
+    model, _ = _model(size, golden_state_dict(g))
+    x = images.to(DEV)
+    ref = model(x)
+    model.export()
+    coords, logits = model(x)
+    assert torch.equal(coords, ref["pred_boxes"]) and torch.equal(logits, ref["pred_logits"])
+    assert coords.shape == (2, 100, 4) and logits.shape == (2, 100, 91)
+
+
+@pytest.mark.parametrize("fp16_eval", [False, True])
+def test_evaluate_loop_contract(fp16_eval):
+    """B2: the calling sequence of the reference's engine.evaluate (engine.py:93-164) on the real HIP model - model.eval(),
+    optional model.half() + samples.tensors.half() (fp16_eval), NestedTensor samples moved with .to(device), outputs cast
+    back with .float(), criterion(outputs, targets), postprocessors['bbox'](outputs, orig_target_sizes), results keyed by
+    image id for CocoEvaluator.update. (tests/test_reference_boundary.py runs the reference's own loop against these
+    objects in the build container; this is the same sequence with the GPU forward.)"""
+    g = load_golden("small_padded")
+    size, images, mask = case_batch("small_padded")
+    model, post = _model(size, golden_state_dict(g))
+    model.eval()
+    if fp16_eval:
+        model.half()
+    updates = {}
+    loader = [(lwdetr_amd.models.NestedTensor(images, mask),
+               [{"image_id": torch.tensor(7), "orig_size": torch.tensor([480, 640])},
+                {"image_id": torch.tensor(9), "orig_size": torch.tensor([480, 640])}])]
+    for samples, targets in loader:
+        samples = samples.to(DEV)
+        targets = [{k: v.to(DEV) for k, v in t.items()} for t in targets]
+        if fp16_eval:
+            samples.tensors = samples.tensors.half()
+        outputs = model(samples)
+        if fp16_eval:
+            for key in outputs.keys():
+                if key == "enc_outputs":
+                    for sk in outputs[key].keys():
+                        outputs[key][sk] = outputs[key][sk].float()
+                elif key == "aux_outputs":
+                    for idx in range(len(outputs[key])):
+                        for sk in outputs[key][idx].keys():
+                            outputs[key][idx][sk] = outputs[key][idx][sk].float()
+                else:
+                    outputs[key] = outputs[key].float()
+        assert outputs["pred_logits"].dtype == (torch.float32)
+        orig = torch.stack([t["orig_size"] for t in targets], dim=0)
+        results = post["bbox"](outputs, orig)
+        updates.update({t["image_id"].item(): o for t, o in zip(targets, results)})
+    assert sorted(updates) == [7, 9]
+    sc = torch.stack([updates[k]["scores"] for k in (7, 9)]).float().cpu().numpy()
+    tol = 2e-2 if fp16_eval else 1e-4
+    assert np.abs(sc - g["post_scores"]).max() < tol
+    from lwdetr_amd import dist as D
+    recs = D.to_coco_results(torch.tensor([7, 9]), *(torch.stack([updates[k][f] for k in (7, 9)]).cpu()
+                                                      for f in ("scores", "labels", "boxes")))
+    assert len(recs) == 600 and recs[0]["image_id"] == 7 and len(recs[0]["bbox"]) == 4
+
+
+def test_hip_graph_is_isolated_from_eager_calls_of_the_same_shape():
+    """a captured graph owns a private launch plan. A padded NestedTensor run eagerly at the same
+    padded shape between two replays must not leak its masks / valid ratios / proposals into the graph, and the eager
+    result must not be disturbed by the replays."""
+    g = load_golden("small_padded")
+    size, images, mask = case_batch("small_padded")
+    model, _ = _model(size, golden_state_dict(g))
+    dense = images.to(DEV)
+    graphed = model.capture(dense)
+    r1 = {k: v.clone() for k, v in graphed(dense).items() if isinstance(v, torch.Tensor)}
+    padded = model(lwdetr_amd.models.NestedTensor(dense, mask.to(DEV)))
+    p_logits = padded["pred_logits"].clone()
+    assert np.abs(p_logits.cpu().numpy() - g["pred_logits"]).max() < FP32_TOL          # eager padded call is the golden
+    r2 = graphed(dense)
+    assert torch.equal(r1["pred_logits"], r2["pred_logits"]) and torch.equal(r1["pred_boxes"], r2["pred_boxes"])
+    eager_dense = model(dense)
+    assert torch.equal(eager_dense["pred_logits"], r2["pred_logits"])
+    assert (r2["pred_logits"] - p_logits).abs().max().item() > 1e-3                        # padding does change the result

@@ -1,5 +1,7 @@
 """GPU: the HIP deformable-attention op behind the reference's operator API, against the reference's KAT vectors
 (models/ops/test.py), the C restatement oracle and size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -89,15 +91,16 @@ def test_properties_full_size_and_contract():
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2e-2)])
-@pytest.mark.parametrize("lp", [(1, 2), (2, 4)])
+@pytest.mark.parametrize("lp", [(1, 2), (2, 4), (4, 4), (3, 1)])
 def test_fused_module_matches_oracle_module(dtype, tol, lp):
-    """MSDeformAttn module (fused prologue kernel) vs the torch restatement of ms_deform_attn.py:96-144."""
+    """MSDeformAttn module vs the torch restatement of ms_deform_attn.py:96-144: the (L, P) pairs of the five models on
+    the fused prologue kernel, the module's own defaults (4, 4) and an odd pair on the generic operator."""
     from lwdetr_amd.ops import MSDeformAttn
     from lwdetr_amd.synth import synth_state_dict
     from oracle import lwdetr_torch as O
     l, p = lp
     d, m, b, q = 256, 16, 2, 50
-    shapes = [(20, 24), (10, 12)][:l]
+    shapes = [(20, 24), (10, 12), (5, 6), (3, 3)][:l]
     s = sum(h * w for h, w in shapes)
     mod = MSDeformAttn(d, l, m, p)
     sd = synth_state_dict(mod.state_dict(), seed=5)
@@ -113,6 +116,39 @@ def test_fused_module_matches_oracle_module(dtype, tol, lp):
     mod = mod.to(DEV).to(dtype)
     out = mod(query.to(DEV, dtype), ref_in.to(DEV, dtype), memory.to(DEV, dtype), sh, _lsi(sh), mask.to(DEV))
     assert (out.float().cpu() - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item())
+
+
+def test_core_pytorch_signature_and_native_module_name():
+    """a18 / B4: `ms_deform_attn_core_pytorch(value (N,M,D,S), shapes, loc, weights (N,Lq,M,L*P))` - the reference's debug
+    core signature (models/ops/functions/ms_deform_attn_func.py:52-75) - and the native module imported BY ITS REFERENCE
+    NAME from lw-detr_amd/compat (models/ops/src/vision.cpp:13-16: ms_deform_attn_forward / _backward, positional
+    arguments as the pybind functions take them), both against the reference's known-answer vectors."""
+    import importlib
+    import sys
+    from helpers import ROOT
+    from lwdetr_amd.ops import ms_deform_attn_core_pytorch
+    sys.path.insert(0, os.path.join(ROOT, "lw-detr_amd", "compat"))
+    try:
+        MSDA = importlib.import_module("MultiScaleDeformableAttention")
+    finally:
+        sys.path.pop(0)
+    assert MSDA.__file__.endswith(os.path.join("compat", "MultiScaleDeformableAttention.py"))
+    g = load_golden("msda_op_kat")
+    v = torch.from_numpy(g["oob_value"]).to(DEV)
+    sh = torch.from_numpy(g["oob_shapes"]).to(DEV)
+    loc = torch.from_numpy(g["oob_loc"]).to(DEV)
+    aw = torch.from_numpy(g["oob_aw"]).to(DEV)
+    exp = torch.from_numpy(g["oob_out"]).to(DEV)
+    n, s_, m_, d_ = v.shape
+    out_mod = MSDA.ms_deform_attn_forward(v, sh, _lsi(sh), loc, aw, 2)
+    assert (out_mod - exp).abs().max().item() < 1e-5
+    lq, l_, p_ = loc.shape[1], loc.shape[3], loc.shape[4]
+    out_core = ms_deform_attn_core_pytorch(v.permute(0, 2, 3, 1).contiguous(), [tuple(x) for x in sh.tolist()], loc,
+                                           aw.reshape(n, lq, m_, l_ * p_))
+    assert torch.equal(out_core, out_mod)
+    gout = torch.ones_like(out_mod)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, _lsi(sh), loc, aw, gout, 2)
+    assert gv.shape == v.shape and gl.shape == loc.shape and ga.shape == aw.shape
 
 
 # ---------------------------------------------------------------------------------------------- backward (SURVEY 8(f) row 2)

@@ -51,6 +51,25 @@ def test_mixed_size_batch_strided_rows_and_upscaling_bit_exact_vs_oracle():
     assert torch.equal(out3[0].cpu(), ref[0])
 
 
+def test_table_cache_is_per_axis_length_and_bounded():
+    """resample tables are cached per axis length (x: width, y: height) in one growable device buffer; a
+    stream of distinct sizes neither re-uploads old tables nor grows without bound, and a wrapped cache stays exact."""
+    rng = np.random.default_rng(5)
+    tf = infer_transforms(320, dtype=torch.float32, device=DEV)
+    tf._axis_cap = 6                                   # force the LRU restart path quickly
+    first = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    ref0, _ = P.preprocess([first], 320, torch.float32)
+    ptr = tf._table_dev.data_ptr()
+    for k in range(12):
+        h, w = 64 + 7 * k, 80 + 5 * k
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out, _ = tf([torch.from_numpy(im).to(DEV), torch.from_numpy(first).to(DEV)])
+        ref, _ = P.preprocess([im], 320, torch.float32)
+        assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref0[0]), k
+        assert len(tf._axis) <= 6
+    assert tf._table_dev.data_ptr() == ptr             # same device buffer throughout: nothing re-concatenated
+
+
 def test_feeds_the_model_end_to_end():
     """uint8 frames -> preprocess -> LWDETR -> PostProcess, all on the device; fp32 result equals the oracle pipeline."""
     from lwdetr_amd.synth import synth_state_dict

@@ -8,7 +8,7 @@ from oracle import lwdetr_torch as O
 from helpers import CASES, case_batch, golden_state_dict, load_golden, sample_idx
 
 FAST = ["tiny_640", "tiny_192x256", "small_padded", "large_padded", "medium_640"]
-SLOW = ["small_640", "large_640", "xlarge_640"]
+SLOW = ["small_640", "large_640", "xlarge_640", "xlarge_960"]
 
 
 def _check(name):
