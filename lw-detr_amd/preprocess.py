@@ -71,6 +71,7 @@ class SquareResizeNormalize:
         self._axis_cap = 1024
         self._table_dev = torch.empty(1 << 20, dtype=torch.int32, device=self.device)
         self._table_len = 0
+        self._gen = 0                       # bumped whenever the buffer is started over (offsets handed out before are void)
 
     def _axis_table(self, n):
         ent = self._axis.pop(n, None)
@@ -83,6 +84,7 @@ class SquareResizeNormalize:
                 # full: start over (the launches of earlier calls are already ordered before this upload on the stream)
                 self._axis.clear()
                 self._table_len = 0
+                self._gen += 1
             off = self._table_len
             self._table_dev[off:off + flat.size].copy_(torch.from_numpy(flat))
             self._table_len += flat.size
@@ -90,12 +92,16 @@ class SquareResizeNormalize:
         self._axis[n] = ent                                                    # most recently used last
         return ent
 
-    def _offsets(self, h, w):
-        xo = self._axis_table(w)
-        yo = self._axis_table(h)
-        if w not in self._axis:              # the second lookup started the buffer over: the x table went with it
-            xo = self._axis_table(w)
-        return xo + yo
+    def _offsets_batch(self, shapes):
+        """(h, w) per image -> (xbounds, xcoef, xksize, ybounds, ycoef, yksize) offsets, all valid at the same time."""
+        lengths = {n for hw in shapes for n in hw}
+        self._axis_cap = max(self._axis_cap, 2 * len(lengths))
+        for _ in range(3):
+            gen = self._gen
+            offs = [self._axis_table(w) + self._axis_table(h) for h, w in shapes]
+            if self._gen == gen:             # no restart while collecting: every offset of the batch is live
+                return offs
+        raise RuntimeError("resample table cache: batch does not fit")
 
     @torch.no_grad()
     def __call__(self, images):
@@ -112,7 +118,7 @@ class SquareResizeNormalize:
         b, s = len(imgs), self.size
         descs = (ResizeImage * max(b, 1))()
         tmp_off = 0
-        offs = [self._offsets(int(im.shape[0]), int(im.shape[1])) for im in imgs]
+        offs = self._offsets_batch([(int(im.shape[0]), int(im.shape[1])) for im in imgs])
         for d, im, o in zip(descs, imgs, offs):
             h, w = int(im.shape[0]), int(im.shape[1])
             d.src, d.height, d.width, d.row_stride = im.data_ptr(), h, w, im.stride(0)

@@ -28,13 +28,16 @@ CONFIGS = [("small_b32_fp16", "small", 640, 32, torch.float16),
            ("medium_b64_bf16", "medium", 640, 64, torch.bfloat16),
            ("large_b32_fp16", "large", 640, 32, torch.float16),
            ("xlarge960_b16_fp16", "xlarge", 960, 16, torch.float16)]
-# teacher-forced max |d logits|, max |d boxes| (cxcywh, image = 1), mean |d logits|; free-running: min matched fraction,
-# max |d score| and max |d box| (pixels of a 640 x 480 target) over the matched detections
+# teacher-forced: max |d logits|, max |d boxes| (cxcywh, image = 1), mean |d logits|  -  measured on MI355X (round 2):
+#   small fp16 0.030 / 0.0044 / 0.0023, medium bf16 0.237 / 0.020 / 0.018, large fp16 0.041 / 0.0025 / 0.0026,
+#   xlarge 960 fp16 0.057 / 0.0076 / 0.0032 (logits span -9.7 .. -0.1, std 1.0); every bound is <= 2x its measurement.
+# free-running: `found` = min fraction of the oracle's detections reported with the same label and every box coordinate
+# within `px` pixels of a 640 x 480 target, `score` = max |d score| over those.
 _BOUNDS = {
-    "small_b32_fp16": dict(logit_max=0.15, box_max=0.03, logit_mean=0.01, matched=0.90, score=0.02, box_px=8.0),
-    "medium_b64_bf16": dict(logit_max=0.8, box_max=0.16, logit_mean=0.06, matched=0.80, score=0.08, box_px=30.0),
-    "large_b32_fp16": dict(logit_max=0.15, box_max=0.03, logit_mean=0.01, matched=0.90, score=0.02, box_px=8.0),
-    "xlarge960_b16_fp16": dict(logit_max=0.25, box_max=0.05, logit_mean=0.02, matched=0.85, score=0.03, box_px=12.0),
+    "small_b32_fp16": dict(logit_max=0.06, box_max=0.009, logit_mean=0.0045, found=0.5, score=0.06, px=2.0),
+    "medium_b64_bf16": dict(logit_max=0.47, box_max=0.04, logit_mean=0.036, found=0.3, score=0.1, px=8.0),
+    "large_b32_fp16": dict(logit_max=0.08, box_max=0.005, logit_mean=0.0052, found=0.5, score=0.06, px=2.0),
+    "xlarge960_b16_fp16": dict(logit_max=0.11, box_max=0.015, logit_mean=0.0064, found=0.5, score=0.06, px=2.0),
 }
 
 
@@ -63,23 +66,29 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
     sizes = torch.tensor([[480.0, 640.0]] * batch, device=DEV)
     res_ = post["bbox"](free, sizes)
     ov = np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(col["topk_idx"].cpu().numpy(), exp["topk_idx"])])
-    matched, dscore, dbox, total = 0, 0.0, 0.0, 0
+    # a detection of the oracle counts as FOUND when the model reports the same label with every box coordinate within
+    # `px` pixels (pixel distance, not IoU: with random weights many boxes are a few pixels wide and IoU is hypersensitive)
+    found, dscore, total, ious = 0, 0.0, 0, []
+    px = _BOUNDS[name]["px"]
     for i in range(batch):
         s_o, l_o, b_o = exp["post_scores"][i], exp["post_labels"][i], exp["post_boxes"][i]
         s_m = res_[i]["scores"].float().cpu().numpy()
         l_m = res_[i]["labels"].cpu().numpy()
         b_m = res_[i]["boxes"].float().cpu().numpy()
         top = np.argsort(-s_o)[:100]                           # the oracle's 100 most confident detections of the image
-        iou = box_iou_xyxy(b_o[top], b_m)
-        iou = np.where(l_o[top][:, None] == l_m[None, :], iou, -1.0)
-        j = iou.argmax(1)
-        ok = iou[np.arange(len(top)), j] >= 0.9
+        dist = np.abs(b_o[top][:, None, :] - b_m[None, :, :]).max(-1)
+        dist = np.where(l_o[top][:, None] == l_m[None, :], dist, np.inf)
+        j = dist.argmin(1)
+        ok = dist[np.arange(len(top)), j] <= px
         total += len(top)
-        matched += int(ok.sum())
+        found += int(ok.sum())
         if ok.any():
             dscore = max(dscore, float(np.abs(s_o[top][ok] - s_m[j][ok]).max()))
-            dbox = max(dbox, float(np.abs(b_o[top][ok] - b_m[j][ok]).max()))
-    m.update({"topk_set_overlap": float(ov), "matched": matched / total, "score": dscore, "box_px": dbox,
+            iou = box_iou_xyxy(b_o[top][ok], b_m[j][ok])
+            ious.append(np.diag(iou))
+    ious = np.concatenate(ious) if ious else np.zeros(1)
+    m.update({"topk_set_overlap": float(ov), "found": found / total, "score": dscore, "match_px": px,
+              "iou_of_found_median": float(np.median(ious)), "iou_of_found_p10": float(np.percentile(ious, 10)),
               "config": {"size": size, "res": res, "batch": batch, "dtype": str(dtype).split(".")[-1]}})
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"parity_config_{name}.json"), "w") as f:
@@ -87,4 +96,4 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
     b = _BOUNDS[name]
     assert torch.isfinite(free["pred_logits"].float()).all()
     assert m["logit_max"] < b["logit_max"] and m["box_max"] < b["box_max"] and m["logit_mean"] < b["logit_mean"], m
-    assert m["matched"] > b["matched"] and m["score"] < b["score"] and m["box_px"] < b["box_px"], m
+    assert m["found"] > b["found"] and m["score"] < b["score"], m

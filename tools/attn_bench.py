@@ -50,9 +50,11 @@ def child(shape):
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
         return child(sys.argv[2])
-    only = sys.argv[1:] or list(SHAPES)
+    only = [a for a in sys.argv[1:] if not a.startswith("--v=")] or list(SHAPES)
+    vsel = [a[4:].split(",") for a in sys.argv[1:] if a.startswith("--v=")]
+    variants = [v for v in VARIANTS if not vsel or v[0].split()[-1] in vsel[0]]
     for shape in only:
-        for name, env in VARIANTS:
+        for name, env in variants:
             e = dict(os.environ, **env)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", shape], env=e, capture_output=True,
                                text=True, timeout=300)
