@@ -108,6 +108,10 @@ typedef struct {
 } lwdetr_gemm_desc;
 
 int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
+/* Kernel selection override for tests / tuning (process-wide): big_mode -1 = default (environment LWDETR_GEMM_BIG, else
+ * shape thresholds), 0 = never use the 256-row large-tile kernel, 2 = use it whenever the shape is legal for it,
+ * 32 / 64 = as 2 with that stage depth. Results do not depend on it beyond f32 summation order. */
+void lwdetr_gemm_tuning(int big_mode);
 
 /* ---- fused softmax(QK^T)V, flash-style, MFMA ------------------------------------------------------------------- */
 typedef struct {

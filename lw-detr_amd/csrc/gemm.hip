@@ -17,6 +17,7 @@
 // Workgroup ids are remapped so that tiles sharing an A row-panel run on the same XCD (private L2).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -67,37 +68,23 @@ __device__ __forceinline__ void store_run(T* dst, const float* x, int cnt, bool 
 
 // ---- shared epilogue: accumulators -> LDS (f32) -> fused bias / activation / scale / LayerScale / residual / masks ->
 // coalesced 16-byte stores in the destination layout of the tile's column segment.
-template <typename T, int BM, int BN>
-__device__ __forceinline__ void gemm_epilogue(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
-                                              f32x4 (&acc)[BN / 32][BM / 32], T* smem, long m0, int n0) {
-    constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
+// Second half of the epilogue, shared by every GEMM kernel: one pass of 64 tile rows, already staged in LDS as f32
+// (ROW orientation: stage[row * (BN + 4) + col]; COL orientation (HEADS_T): stage[col * 68 + row]), is finished by all
+// NTHR threads of the workgroup in runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores; the
+// mode / activation logic lives in a small loop instead of being replicated per accumulator register.
+template <typename T, int BN, int NTHR>
+__device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
+                                                const float* stage, long mbase, int n0) {
     typedef typename Vec<T>::v8 V8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    // ---- epilogue through LDS: accumulators are staged as f32 (64 tile rows per pass), then each thread finishes
-    // runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores, and the mode / activation logic
-    // lives in a small non-unrolled loop instead of being replicated per accumulator register.
-    float* stage = (float*)smem;
+    const int tid = threadIdx.x;
     constexpr int SLD = BN + 4, SLD_T = 64 + 4;
     const int n_end = sg.n_end < d.N ? sg.n_end : d.N;
     T* __restrict__ out = (T*)sg.out;
-    for (int pass = 0; pass < BM / 64; ++pass) {
-        if (BM == 64 || wm == pass) {
-            const int r0 = BM == 64 ? wm * WM : 0;          // first stage row of this wave
-            float* sp = col_orient ? stage + (wn * WN + l15) * SLD_T + r0 + g * 4 : stage + (r0 + l15) * SLD + wn * WN + g * 4;
-            const int fs = col_orient ? 16 * SLD_T : 16, ts = col_orient ? 16 : 16 * SLD;
-#pragma unroll
-            for (int f = 0; f < FT; ++f)
-#pragma unroll
-                for (int t = 0; t < TT; ++t) *(f32x4*)(sp + f * fs + t * ts) = acc[f][t];
-        }
-        __syncthreads();
-        const long mbase = m0 + pass * 64;
+    {
         if (!col_orient) {
             // thread -> fixed 8-column run (col), rows strided by 256 / CPRW: column parameters are loop invariant and
             // fetched with two 16-byte loads each (bias / gamma buffers are padded to a multiple of 8 floats by the host)
-            constexpr int CPRW = BN / 8, RSTEP = 256 / CPRW;
+            constexpr int CPRW = BN / 8, RSTEP = NTHR / CPRW;
             T* __restrict__ out2 = (T*)sg.out2;
             const T* __restrict__ res = (const T*)sg.res;
             const int col = (tid % CPRW) * 8, n = n0 + col;
@@ -168,7 +155,7 @@ __device__ __forceinline__ void gemm_epilogue(const lwdetr_gemm_desc& d, const l
             // HEADS_T: out[((b*heads+h)*hd+dd)*Tp + t]: runs of 4 consecutive tokens of one output column
             constexpr int RPC = 64 / 4;
 #pragma unroll 1
-            for (int c = tid; c < BN * RPC; c += 256) {
+            for (int c = tid; c < BN * RPC; c += NTHR) {
                 const int coln = c / RPC, row = (c - coln * RPC) * 4;
                 const long m = mbase + row;
                 const int n = n0 + coln;
@@ -184,6 +171,31 @@ __device__ __forceinline__ void gemm_epilogue(const lwdetr_gemm_desc& d, const l
                 store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
             }
         }
+    }
+}
+
+// ---- epilogue of the 4-wave (2 x 2) kernels: accumulators -> LDS (f32, 64 tile rows per pass) -> epilogue_finish
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
+                                              f32x4 (&acc)[BN / 32][BM / 32], T* smem, long m0, int n0) {
+    constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    float* stage = (float*)smem;
+    constexpr int SLD = BN + 4, SLD_T = 64 + 4;
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        if (BM == 64 || wm == pass) {
+            const int r0 = BM == 64 ? wm * WM : 0;          // first stage row of this wave
+            float* sp = col_orient ? stage + (wn * WN + l15) * SLD_T + r0 + g * 4 : stage + (r0 + l15) * SLD + wn * WN + g * 4;
+            const int fs = col_orient ? 16 * SLD_T : 16, ts = col_orient ? 16 : 16 * SLD;
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) *(f32x4*)(sp + f * fs + t * ts) = acc[f][t];
+        }
+        __syncthreads();
+        epilogue_finish<T, BN, 256>(d, sg, col_orient, stage, m0 + pass * 64, n0);
         __syncthreads();
     }
 }
@@ -633,6 +645,213 @@ __global__ __launch_bounds__(256) void gemm_apanel_kernel(const lwdetr_gemm_desc
     wait_vmcnt<0>();                     // the dummy tail pieces target LDS: they must land before the workgroup retires
 }
 
+// ---- large-tile variant for the compute-bound GEMMs (C = 384 / 768 models: K >= 384, tens of thousands of rows) -----
+// 512 threads = 8 waves, block tile 256 x BN (BN = 256: 2 x 4 waves of 128 x 64; BN = 128: 4 x 2 waves of 64 x 64),
+// 32x32x16 MFMAs (a 1 KB operand fragment feeds 16384 MACs: half the LDS reads per FLOP of the 16x16x32 form at these
+// wave tiles), operands through an NST-deep DMA ring of KB-deep stages exactly like gemm_dma_kernel (counted vmcnt, one raw
+// barrier per stage, source-side XOR swizzle). Why a second kernel: a 64 x 64 tile pulls (64 + 64) x K x 2 bytes into the CU
+// for 64 x 64 x K MACs - 4x the ingress per FLOP of a 256 x 256 tile - and these shapes are bound by exactly that (C = 768:
+// 375 TFLOP/s with 64 x 64, 430 with 128 x 128). LDS swizzle for the 32-row fragments (lane -> row = lane & 31, 16-byte
+// k-slot 2 kc + (lane >> 5)): slot ^= (row >> 2) & 3 at KB = 32, (row >> 1) & 7 at KB = 64 - conflict-free for the 16-lane
+// ds_read_b128 service groups (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}).
+template <typename T> struct Mma32;
+template <> struct Mma32<f16> {
+    static __device__ __forceinline__ f32x16 k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32<bf16> {
+    static __device__ __forceinline__ f32x16 k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, int BN, int KB, int NST>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d) {
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    constexpr int BM = 256, EPC = 8;
+    constexpr int WGN = BN / 64, WGM = 8 / WGN;                   // wave grid: columns of 64, rows of BM / WGM
+    constexpr int WM = BM / WGM, WN = 64, TM = WM / 32, TN = WN / 32;
+    constexpr int SLOTS = KB / EPC, RP = 64 / SLOTS, KC = KB / 16;
+    constexpr int A_MY = BM / RP / 8, B_MY = BN / RP / 8, PER_STAGE = A_MY + B_MY;
+    constexpr int STAGE = (BM + BN) * KB;                         // elements
+    typedef typename Vec<T>::v8 V8;
+    extern __shared__ __attribute__((aligned(16))) char big_smem[];
+    T* smem = (T*)big_smem;
+
+    const int tiles_n = (d.N + BN - 1) / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm_ = wg / tiles_n, tn_ = wg - tm_ * tiles_n;
+    const long m0 = (long)tm_ * BM;
+    const int n0 = tn_ * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const T* __restrict__ A = (const T*)d.A;
+    const T* __restrict__ W = (const T*)d.W;
+    const T* zero = (const T*)g_zero16;
+
+    // DMA pieces of this wave (piece i covers tile rows RP i .. RP i + RP - 1; lane -> row i RP + lane / SLOTS, physical slot
+    // lane % SLOTS; the logical 16-byte column it fetches is the slot un-swizzled with the row's key). Pieces 0 .. A_MY - 1
+    // are A rows, the rest W rows; rows past M / N read the zero page (step 0). The DMA goes through inline assembly
+    // (gdma16: invisible to hipcc, so pending pieces do not turn its ds_read waits into lgkmcnt(0)) and the pieces of a
+    // stage are issued two at a time BETWEEN the MFMA groups of the previous stage: issued in one burst after the barrier
+    // they cost ~100 issue cycles each with both waves of a SIMD stalled behind them (kb64: 8 pieces per wave and stage).
+    const int prow = lane / SLOTS, pslot = lane % SLOTS;
+    auto key_of = [](int row) { return KB == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
+    const T* psrc[PER_STAGE]; int pstep[PER_STAGE];
+#pragma unroll
+    for (int k = 0; k < PER_STAGE; ++k) {
+        const bool is_a = k < A_MY;
+        const int row = RP * (wave + 8 * (is_a ? k : k - A_MY)) + prow;
+        const long gr = (is_a ? m0 : (long)n0) + row;
+        const bool ok = gr < (is_a ? d.M : (long)d.N);
+        const T* base = is_a ? A + gr * d.lda : W + gr * (long)d.K;
+        psrc[k] = ok ? base + (pslot ^ key_of(row)) * EPC : zero;
+        pstep[k] = ok ? KB : 0;
+    }
+    const int nk = d.K / KB;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)big_smem;
+    const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * EPC * (int)sizeof(T));
+    // issue piece k of stage kt (stages past the end of K read the zero page: the wait counts stay compile-time constants)
+    auto issue_piece = [&](int kt, int k) {
+        const bool is_a = k < A_MY;
+        const unsigned dst = lds0 + (unsigned)((kt % NST) * STAGE + (is_a ? 0 : BM * KB)) * (unsigned)sizeof(T) + wave_off +
+                             (unsigned)(8 * (is_a ? k : k - A_MY) * 64 * EPC * (int)sizeof(T));
+        const T* src = kt < nk ? psrc[k] + (long)kt * pstep[k] : zero;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
+    };
+
+    int si = 0;
+#pragma unroll
+    for (int s = 1; s < 3; ++s) if (s < d.nseg && n0 >= d.seg[s].n_begin) si = s;
+    const lwdetr_gemm_seg& sg = d.seg[si];
+    const bool col_orient = sg.mode == LWDETR_OUT_HEADS_T;
+
+    int pofs[KC];                            // element offset of this lane's k-run inside its row, per 16-deep chunk
+#pragma unroll
+    for (int c = 0; c < KC; ++c) pofs[c] = ((2 * c + h) ^ key_of(m)) * EPC;
+    const int arow = (wm * WM + m) * KB, brow = (wn * WN + m) * KB;
+    float* stg = (float*)big_smem;
+    constexpr int SLD = BN + 4, SLD_T = 64 + 4;
+
+    // The whole k-loop + accumulator staging is instantiated once per MFMA operand order (a branch on the orientation
+    // inside the loop made hipcc keep both orders alive and spill the 128 accumulator registers around every MFMA group).
+    auto body = [&](auto col_tag) {
+        constexpr bool COL = decltype(col_tag)::value;
+        f32x16 acc[TN][TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < NST - 1; ++s_)
+#pragma unroll
+            for (int k = 0; k < PER_STAGE; ++k) issue_piece(s_, k);
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<(NST - 2) * PER_STAGE>();           // stage kt has landed (this wave's pieces) ...
+            __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody has also left stage kt - 1
+            const T* As = smem + (kt % NST) * STAGE;
+            const T* Bs = As + BM * KB;
+            V8 xf[2][TM], wf[2][TN];                       // fragments of chunk c + 1 are read while chunk c multiplies
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xf[0][i] = *(const V8*)(As + arow + i * 32 * KB + pofs[0]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[0][j] = *(const V8*)(Bs + brow + j * 32 * KB + pofs[0]);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c + 1 < KC) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) xf[(c + 1) & 1][i] = *(const V8*)(As + arow + i * 32 * KB + pofs[c + 1]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) wf[(c + 1) & 1][j] = *(const V8*)(Bs + brow + j * 32 * KB + pofs[c + 1]);
+                }
+#pragma unroll
+                for (int k = c; k < PER_STAGE; k += KC) issue_piece(kt + NST - 1, k);   // refill the buffer stage kt - 1 used
+                __builtin_amdgcn_sched_barrier(0);   // reads of chunk c + 1 and the DMA issue stay AHEAD of chunk c's MFMAs
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)     // ROW: D[n][m], lane holds 4 consecutive n of one row m; COL: D[m][n]
+                        acc[j][i] = COL ? Mma32<T>::k16(xf[c & 1][i], wf[c & 1][j], acc[j][i])
+                                        : Mma32<T>::k16(wf[c & 1][j], xf[c & 1][i], acc[j][i]);
+            }
+        }
+        wait_vmcnt<0>();        // the dummy tail pieces (hipcc does not know about them)
+        __syncthreads();        // drains the dummy tail pieces and the last fragment reads before LDS is re-used
+        // ---- epilogue: passes of 64 rows through the f32 stage area (aliases the ring), finished by all 512 threads.
+        // 32x32 accumulator: register 4 q + r of lane (c = lane & 31, hi) is element (row 8 q + 4 hi + r, column c) of D.
+#pragma unroll 1
+        for (int pass = 0; pass < BM / 64; ++pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (wm * (WM / 64) + (i >> 1) != pass) continue;        // wave-uniform: this tile's rows belong to the pass
+                const int ii = i & 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]};
+                        if (!COL)    // lane: row ii * 32 + (lane & 31), columns wn WN + 32 j + 8 q + 4 hi .. + 3
+                            *(f32x4*)(stg + (ii * 32 + m) * SLD + wn * WN + j * 32 + q * 8 + h * 4) = v;
+                        else         // lane: column wn WN + 32 j + (lane & 31), rows ii * 32 + 8 q + 4 hi .. + 3
+                            *(f32x4*)(stg + (wn * WN + j * 32 + m) * SLD_T + ii * 32 + q * 8 + h * 4) = v;
+                    }
+            }
+            __syncthreads();
+            epilogue_finish<T, BN, 512>(d, sg, COL, stg, m0 + pass * 64, n0);
+            __syncthreads();
+        }
+    };
+    if (col_orient) body(std::true_type{});
+    else body(std::false_type{});
+}
+
+template <typename T, int BN, int KB, int NST>
+int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
+    constexpr size_t ring = (size_t)NST * (256 + BN) * KB * sizeof(T);
+    constexpr size_t stg = (size_t)(64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
+    constexpr size_t lds = ring > stg ? ring : stg;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        done = true;
+    }
+    const long nwg = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST>), dim3((unsigned)nwg), dim3(512), lds, st, d);
+    return lwdetr_check_launch();
+}
+
+// Shapes the large-tile kernel takes: plain A, no A2, K a multiple of 64, segment boundaries on the column tile, and (mode 1,
+// the default) enough work for 256-row tiles to fill the chip. LWDETR_GEMM_BIG / lwdetr_gemm_tuning(): 0 = never, 1 = default
+// thresholds, 2 = whenever legal (tests), 32 / 64 = whenever legal with that stage depth (tuning).
+int g_big_mode = -1;
+template <typename T>
+int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
+    taken = false;
+    if constexpr (sizeof(T) != 2) return LWDETR_OK;
+    else {
+        static const char* env = getenv("LWDETR_GEMM_BIG");
+        const int mode = g_big_mode >= 0 ? g_big_mode : (env ? atoi(env) : 1);
+        if (!mode || d.a_mode != LWDETR_A_PLAIN || d.A2 || d.K % 64 != 0) return LWDETR_OK;
+        if (mode == 1 && (d.K < 384 || d.M < 16384 || d.N < 256)) return LWDETR_OK;       // measured crossover: see launch()
+        bool bn256 = d.N % 256 == 0 || d.N > 512;
+        for (int s = 0; s < d.nseg; ++s) {
+            if (d.seg[s].n_begin % 128 != 0) return LWDETR_OK;
+            if (d.seg[s].n_begin % 256 != 0) bn256 = false;
+        }
+        if (d.N < 128) return LWDETR_OK;
+        taken = true;
+        const int variant = mode >= 10 ? mode : 0;     // tuning: 32 / 64 = stage depth (ring 4 / 2 deep)
+        if (bn256) return variant == 32 ? launch_big<T, 256, 32, 4>(d, st) : launch_big<T, 256, 64, 2>(d, st);
+        return variant == 32 ? launch_big<T, 128, 32, 4>(d, st) : launch_big<T, 128, 64, 3>(d, st);
+    }
+}
+
 template <typename T, int AMODE>
 int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     // column tile: 128 unless a segment boundary (or a small N) asks for 64
@@ -662,6 +881,11 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     if (nwg <= 0 || nwg > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
     const int kid = AMODE == LWDETR_A_PLAIN ? KID_GEMM : (AMODE == LWDETR_A_CONV3x3 ? KID_GEMM_CONV : KID_GEMM_PATCH);
     ProfScope ps(kid, 2.0 * d.M * d.N * d.K, ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) * sizeof(T), st);
+    if constexpr (AMODE == LWDETR_A_PLAIN) {
+        bool taken = false;
+        const int rc = try_launch_big<T>(d, st, taken);
+        if (taken) return rc;
+    }
     if constexpr (sizeof(T) == 2) {
         static const char* env = getenv("LWDETR_GEMM_DMA");
         const int mode = env ? atoi(env) : 3;
@@ -730,6 +954,8 @@ int dispatch_amode(const lwdetr_gemm_desc& d, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" void lwdetr_gemm_tuning(int big_mode) { g_big_mode = big_mode; }
 
 extern "C" int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream) {
     if (!desc) return LWDETR_ERR_BAD_ARG;

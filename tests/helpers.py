@@ -61,7 +61,7 @@ def case_batch(name):
 # ---- CPU oracle over a full BASELINE batch: images are independent, so the batch is cut into small chunks that worker
 # processes (spawned: the parent may hold a GPU context) run side by side on the host cores.
 def _oracle_chunk(job):
-    size, seed, lo, hi, res, img_seed, threads = job
+    size, seed, lo, hi, res, img_seed, threads, forced = job
     import torch as _t
     _t.set_num_threads(threads)
     import lwdetr_amd
@@ -71,23 +71,27 @@ def _oracle_chunk(job):
     model, _, _ = lwdetr_amd.build_model(cfg)
     sd = synth_state_dict(model.state_dict(), seed=seed)
     x = synth_images(hi, res, res, seed=img_seed)[lo:hi]          # counter-based generator: image i is the same in any batch
+    col = {}
     with _t.no_grad():
-        out = O.forward(sd, cfg, x)
+        out = O.forward(sd, cfg, x, forced_topk=None if forced is None else _t.from_numpy(forced), collect=col)
         res_ = O.postprocess(out, _t.tensor([[480.0, 640.0]] * (hi - lo)), cfg.num_select)
         sc, lb, bx = (_t.stack([r[k] for r in res_]) for k in ("scores", "labels", "boxes"))
     return {"pred_logits": out["pred_logits"].numpy(), "pred_boxes": out["pred_boxes"].numpy(),
             "enc_logits": out["enc_outputs"]["pred_logits"].numpy(), "enc_boxes": out["enc_outputs"]["pred_boxes"].numpy(),
-            "topk_idx": out["topk_idx"].numpy(), "post_scores": sc.numpy(), "post_labels": lb.numpy(), "post_boxes": bx.numpy()}
+            "topk_idx": out["topk_idx"].numpy(), "enc_class_max": col["enc.class_max"].numpy(), "post_scores": sc.numpy(), "post_labels": lb.numpy(), "post_boxes": bx.numpy()}
 
 
-def oracle_batch(size, batch, res, img_seed, seed=0, chunk=2):
-    """fp32 CPU oracle outputs for synth_images(batch, res, res, img_seed) with synth weights `seed` (dict of numpy arrays)."""
+def oracle_batch(size, batch, res, img_seed, seed=0, chunk=2, forced_topk=None):
+    """fp32 CPU oracle outputs for synth_images(batch, res, res, img_seed) with synth weights `seed` (dict of numpy arrays).
+    forced_topk (batch, nq) int64 numpy: two-stage indices to use instead of the oracle's own (teacher forcing)."""
     import multiprocessing as mp
     cores = len(os.sched_getaffinity(0))
     jobs_n = (batch + chunk - 1) // chunk
     procs = max(1, min(jobs_n, cores // 8))
     threads = max(1, min(16, cores // procs))
-    jobs = [(size, seed, lo, min(lo + chunk, batch), res, img_seed, threads) for lo in range(0, batch, chunk)]
+    jobs = [(size, seed, lo, min(lo + chunk, batch), res, img_seed, threads,
+             None if forced_topk is None else np.ascontiguousarray(forced_topk[lo:min(lo + chunk, batch)]))
+            for lo in range(0, batch, chunk)]
     if procs == 1:
         parts = [_oracle_chunk(j) for j in jobs]
     else:

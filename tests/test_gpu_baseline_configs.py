@@ -1,15 +1,21 @@
 """GPU: parity of the HIP path at the BASELINE configurations AS STATED - model size x resolution x batch x dtype
 (BASELINE.json configs 2-5; the per-GPU shard of the 8-GPU configs) - against the fp32 CPU oracle run on the same
-synthetic batch in chunks on the host cores (tests/helpers.py:oracle_batch). Two comparisons per config:
+synthetic batch in chunks on the host cores (tests/helpers.py:oracle_batch).
 
-  * teacher-forced: the oracle's two-stage indices are forced, so every one of the B x 300 query slots is comparable:
-    max / mean |difference| of final and encoder logits and boxes;
-  * free-running: the model's own selection, then PostProcess on both sides (models/lwdetr.py:509-544); detections are
-    matched as SETS per image (same label, best IoU): fraction of the oracle's confident detections that are found with
-    IoU >= 0.9, and their score / box differences.
+The model runs FREE (its own two-stage selection), then the oracle is run with that selection forced. Why this way
+round: LW-DETR pairs the k-th selected token with the k-th learned query embedding (models/lwdetr.py:150-155,
+models/transformer.py:246-264), so the ORDER of near-tied top-k scores changes every downstream tensor; 16-bit arithmetic
+reorders near-ties (any 16-bit implementation does), which says nothing about the kernels. Checked per config:
 
-Every bound below is <= 2x the value measured on MI355X (written next to it; the numbers of each run land in
-gpurun_out/parity_config_*.json and the tracked copy is profiles/parity_config_*.json)."""
+  * selection: the oracle's own top-k set vs the model's (overlap), and - with the ORACLE's scores - how much worse the
+    model's picks are than the oracle's (rank-wise score gap): a wrong token would show as a gap above 16-bit noise;
+  * slot-wise: max / mean |difference| of final and encoder logits and boxes over all B x 300 slots;
+  * detections: PostProcess on both sides (models/lwdetr.py:509-544); fraction of the oracle's 100 most confident
+    detections per image that the model reports with the same label and every box coordinate within `px` pixels, and the
+    score differences of those.
+
+Every bound is <= 2x the value measured on MI355X (written next to it; each run writes gpurun_out/parity_config_*.json,
+the tracked copy is profiles/parity_config_*.json)."""
 import json
 import os
 
@@ -28,30 +34,44 @@ CONFIGS = [("small_b32_fp16", "small", 640, 32, torch.float16),
            ("medium_b64_bf16", "medium", 640, 64, torch.bfloat16),
            ("large_b32_fp16", "large", 640, 32, torch.float16),
            ("xlarge960_b16_fp16", "xlarge", 960, 16, torch.float16)]
-# teacher-forced: max |d logits|, max |d boxes| (cxcywh, image = 1), mean |d logits|  -  measured on MI355X (round 2):
-#   small fp16 0.030 / 0.0044 / 0.0023, medium bf16 0.237 / 0.020 / 0.018, large fp16 0.041 / 0.0025 / 0.0026,
-#   xlarge 960 fp16 0.057 / 0.0076 / 0.0032 (logits span -9.7 .. -0.1, std 1.0); every bound is <= 2x its measurement.
-# free-running: `found` = min fraction of the oracle's detections reported with the same label and every box coordinate
-# within `px` pixels of a 640 x 480 target, `score` = max |d score| over those.
+# Measured on MI355X (round 2, profiles/parity_config_*.json); every bound is <= 2x its measurement:
+#                         logit_max  box_max  logit_mean  overlap  gap     found   score
+#   small  B32 fp16        0.0322    0.0035    0.00226    0.9978   0.0037  1.0     0.0030
+#   medium B64 bf16        0.2224    0.0181    0.01797    0.9852   0.0421  0.9998  0.0192
+#   large  B32 fp16        0.0416    0.0037    0.00264    0.9971   0.0049  1.0     0.0035
+#   xlarge 960 B16 fp16    0.0569    0.0089    0.00322    0.9967   0.0026  1.0     0.0031
+# (logits span about -9.7 .. -0.1 with std 1.0; boxes are cxcywh with the image = 1.) logit_max / box_max / logit_mean:
+# slot-wise |difference| of final + encoder outputs; overlap / gap: two-stage selection vs the oracle's, judged with the
+# oracle's scores; found: fraction of the oracle's detections reported with the same label and every box coordinate within
+# `px` pixels of a 640 x 480 target; score: max |d score| over those.
 _BOUNDS = {
-    "small_b32_fp16": dict(logit_max=0.06, box_max=0.009, logit_mean=0.0045, found=0.5, score=0.06, px=2.0),
-    "medium_b64_bf16": dict(logit_max=0.47, box_max=0.04, logit_mean=0.036, found=0.3, score=0.1, px=8.0),
-    "large_b32_fp16": dict(logit_max=0.08, box_max=0.005, logit_mean=0.0052, found=0.5, score=0.06, px=2.0),
-    "xlarge960_b16_fp16": dict(logit_max=0.11, box_max=0.015, logit_mean=0.0064, found=0.5, score=0.06, px=2.0),
+    "small_b32_fp16": dict(logit_max=0.064, box_max=0.007, logit_mean=0.0045, overlap=0.99, gap=0.0075, found=0.98, score=0.006, px=2.0),
+    "medium_b64_bf16": dict(logit_max=0.44, box_max=0.036, logit_mean=0.036, overlap=0.97, gap=0.084, found=0.98, score=0.038, px=8.0),
+    "large_b32_fp16": dict(logit_max=0.083, box_max=0.0074, logit_mean=0.0052, overlap=0.99, gap=0.0098, found=0.98, score=0.007, px=2.0),
+    "xlarge960_b16_fp16": dict(logit_max=0.11, box_max=0.0178, logit_mean=0.0064, overlap=0.99, gap=0.0052, found=0.98, score=0.0062, px=2.0),
 }
 
 
 @pytest.mark.parametrize("name,size,res,batch,dtype", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_baseline_config_parity(name, size, res, batch, dtype):
     from lwdetr_amd.synth import synth_images, synth_state_dict
-    exp = oracle_batch(size, batch, res, img_seed=4321)
     cfg = lwdetr_amd.get_args(size)
     model, _, post = lwdetr_amd.build_model(cfg)
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
     model = model.to(DEV).to(dtype).eval()
     x = synth_images(batch, res, res, seed=4321).to(DEV).to(dtype)
-    # ---- teacher-forced, slot-wise
-    out = model(x, _forced_topk=torch.from_numpy(exp["topk_idx"]).to(DEV))
+    col = {}
+    out = model(x, _collect=col)                                            # free-running
+    ours = col["topk_idx"].cpu().numpy()
+    sizes = torch.tensor([[480.0, 640.0]] * batch, device=DEV)
+    res_ = post["bbox"](out, sizes)
+    exp = oracle_batch(size, batch, res, img_seed=4321, forced_topk=ours)   # fp32 CPU oracle on the model's selection
+    # ---- selection, judged with the oracle's scores
+    ref_sc = exp["enc_class_max"]
+    ref_idx = np.argsort(-ref_sc, axis=1, kind="stable")[:, :cfg.num_queries]
+    ov = np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(ours, ref_idx)])
+    gap = np.abs(np.sort(np.take_along_axis(ref_sc, ours, 1), 1) - np.sort(np.take_along_axis(ref_sc, ref_idx, 1), 1)).max()
+    # ---- slot-wise
     dl = np.abs(out["pred_logits"].float().cpu().numpy() - exp["pred_logits"])
     db = np.abs(out["pred_boxes"].float().cpu().numpy() - exp["pred_boxes"])
     del_ = np.abs(out["enc_outputs"]["pred_logits"].float().cpu().numpy() - exp["enc_logits"])
@@ -59,13 +79,7 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
     m = {"logit_max": float(max(dl.max(), del_.max())), "box_max": float(max(db.max(), deb.max())),
          "logit_mean": float(dl.mean()), "box_mean": float(db.mean()),
          "logit_range": [float(exp["pred_logits"].min()), float(exp["pred_logits"].max())],
-         "logit_std": float(exp["pred_logits"].std())}
-    # ---- free-running: own selection + PostProcess, detections matched as sets
-    col = {}
-    free = model(x, _collect=col)
-    sizes = torch.tensor([[480.0, 640.0]] * batch, device=DEV)
-    res_ = post["bbox"](free, sizes)
-    ov = np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(col["topk_idx"].cpu().numpy(), exp["topk_idx"])])
+         "logit_std": float(exp["pred_logits"].std()), "topk_set_overlap": float(ov), "topk_score_gap": float(gap)}
     # a detection of the oracle counts as FOUND when the model reports the same label with every box coordinate within
     # `px` pixels (pixel distance, not IoU: with random weights many boxes are a few pixels wide and IoU is hypersensitive)
     found, dscore, total, ious = 0, 0.0, 0, []
@@ -87,13 +101,14 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
             iou = box_iou_xyxy(b_o[top][ok], b_m[j][ok])
             ious.append(np.diag(iou))
     ious = np.concatenate(ious) if ious else np.zeros(1)
-    m.update({"topk_set_overlap": float(ov), "found": found / total, "score": dscore, "match_px": px,
+    m.update({"found": found / total, "score": dscore, "match_px": px,
               "iou_of_found_median": float(np.median(ious)), "iou_of_found_p10": float(np.percentile(ious, 10)),
               "config": {"size": size, "res": res, "batch": batch, "dtype": str(dtype).split(".")[-1]}})
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"parity_config_{name}.json"), "w") as f:
         json.dump(m, f, indent=1)
     b = _BOUNDS[name]
-    assert torch.isfinite(free["pred_logits"].float()).all()
+    assert torch.isfinite(out["pred_logits"].float()).all()
+    assert m["topk_set_overlap"] > b["overlap"] and m["topk_score_gap"] < b["gap"], m
     assert m["logit_max"] < b["logit_max"] and m["box_max"] < b["box_max"] and m["logit_mean"] < b["logit_mean"], m
     assert m["found"] > b["found"] and m["score"] < b["score"], m

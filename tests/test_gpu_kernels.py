@@ -50,6 +50,10 @@ def test_gemm_linear_bias_act_res(dtype, mnk):
 def test_gemm_qkv_head_layouts(dtype, hd, b, tp):
     """Three column segments: Q (HEADS, bias, scale), K (HEADS), V^T (HEADS_T, bias) - transpose-detecting data.
     The (32, 1600) / (24, 1600) cases are full-size batches (block 0 of small / medium: A-panel-resident schedule)."""
+    _check_qkv_layouts(dtype, hd, b, tp)
+
+
+def _check_qkv_layouts(dtype, hd, b, tp):
     from lwdetr_amd import kernels as K
     heads = 12
     c = heads * hd
@@ -206,6 +210,48 @@ def test_attention(dtype, hd, geom):
         ref = _attn_ref(qn, k, v, valid)
     err = ((o - ref)[:, :, valid]).abs().max().item()
     assert err < {torch.float32: 2e-5, torch.float16: 6e-3, torch.bfloat16: 4e-2}[dtype], err
+
+
+@pytest.fixture
+def big_gemm():
+    """Route every legal GEMM through the 256-row large-tile kernel (by default only large shapes take it)."""
+    from lwdetr_amd import _native
+    _native.lib().lwdetr_gemm_tuning(2)
+    yield
+    _native.lib().lwdetr_gemm_tuning(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mnk,depth", [((1000, 768, 768), 2), ((4099, 256, 3072), 2), ((2048, 3072, 768), 64), ((777, 384, 384), 32),
+                                       ((513, 128, 1536), 2), ((300, 640, 1024), 32)])
+def test_gemm_large_tile_kernel(dtype, mnk, depth):
+    """gemm_big_kernel (256 x 256 / 256 x 128 tiles, 32x32x16 MFMA, DMA ring of 32- and 64-deep stages) vs torch: bias,
+    GELU, LayerScale + residual epilogue; ragged M and N tails."""
+    from lwdetr_amd import _native, kernels as K
+    m, n, k = mnk
+    x = _rand(m, k, dtype=dtype, seed=1)
+    w = _rand(n, k, dtype=dtype, scale=k ** -0.5, seed=2)
+    bias = _rand(n, dtype=torch.float32, seed=3)
+    gamma = _rand(n, dtype=torch.float32, seed=4)
+    res = _rand(m, n, dtype=dtype, seed=5)
+    _native.lib().lwdetr_gemm_tuning(depth)
+    try:
+        out = K.linear(x, w, bias, act=K.ACT_GELU, res=res, gamma=gamma)
+        plain = K.linear(x, w, bias)
+    finally:
+        _native.lib().lwdetr_gemm_tuning(-1)
+    base = K.linear(x, w, bias)                              # default kernel choice (64 x 64 tiles at these sizes)
+    y = x.float() @ w.float().t() + bias
+    ref = res.float() + gamma * torch.nn.functional.gelu(y)
+    assert _relerr(out, ref) < TOL[dtype]
+    assert _relerr(plain, y) < TOL[dtype]
+    assert _relerr(plain, base.float()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_large_tile_kernel_head_layouts(dtype, big_gemm):
+    """QKV of the C = 768 model through the large-tile kernel: HEADS (q, k) and HEADS_T (V^T, swapped MFMA operands)."""
+    _check_qkv_layouts(dtype, 64, 4, 1600)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

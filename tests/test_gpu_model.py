@@ -68,8 +68,18 @@ def test_fp32_matches_reference_golden(name, mlp_path):
     assert max(d.values()) < FP32_TOL, d
     # PostProcess on the HIP outputs reproduces the reference's detections
     res = post["bbox"](out, torch.tensor([[480.0, 640.0]] * images.shape[0], device=DEV))
-    assert np.abs(torch.stack([r["scores"] for r in res]).cpu().numpy() - g["post_scores"]).max() < 1e-4
-    assert (torch.stack([r["labels"] for r in res]).cpu().numpy() == g["post_labels"]).mean() > 0.99
+    sc = torch.stack([r["scores"] for r in res]).cpu().numpy()
+    lb = torch.stack([r["labels"] for r in res]).cpu().numpy()
+    bx = torch.stack([r["boxes"] for r in res]).cpu().numpy()
+    assert np.abs(sc - g["post_scores"]).max() < 1e-4
+    # labels AND boxes, rank by rank; a rank may differ only where the reference's own scores are tied to fp32 noise, and then
+    # the same (label, box) must sit at a tied neighbouring rank of the reference list
+    for i in range(sc.shape[0]):
+        same = (lb[i] == g["post_labels"][i]) & (np.abs(bx[i] - g["post_boxes"][i]).max(-1) < 0.05)
+        for k in np.nonzero(~same)[0]:
+            tied = np.nonzero(np.abs(g["post_scores"][i] - g["post_scores"][i][k]) < 2e-5)[0]
+            hit = [(g["post_labels"][i][t] == lb[i][k]) and np.abs(g["post_boxes"][i][t] - bx[i][k]).max() < 0.05 for t in tied]
+            assert len(tied) > 1 and any(hit), (name, i, int(k), float(g["post_scores"][i][k]))
 
 
 @pytest.mark.parametrize("name", ["tiny_640", "small_padded", "large_padded"])
