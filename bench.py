@@ -214,8 +214,7 @@ def main():
 
     def step():
         out = model(images)
-        s, l, b = pp.select(out["pred_logits"], out["pred_boxes"], sizes)
-        det = ldist.pack_detections(s, l, b)
+        det = pp.select_packed(out["pred_logits"], out["pred_boxes"], sizes)      # PostProcess -> (B, K, 6) records
         return ldist.all_gather_detections(det, gathered)
 
     def barrier():
@@ -243,7 +242,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(a.steps):
             out = model(images)
-            ldist.pack_detections(*pp.select(out["pred_logits"], out["pred_boxes"], sizes))
+            pp.select_packed(out["pred_logits"], out["pred_boxes"], sizes)
         barrier()
         tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -297,13 +296,15 @@ def main():
         # this workload (tools/profile_round.sh -> profiles/hbm_traffic*.json) and labelled as such
         traffic, tsrc = None, None
         wl = f"{a.size}_b{a.batch}_{a.res}_{a.dtype}"
-        for tf in (f"hbm_traffic_{wl}.json", "hbm_traffic.json" if wl == "small_b32_640_fp16" else None):
-            tfp = os.path.join(ROOT, "profiles", tf) if tf else None
-            if tfp and os.path.exists(tfp):
-                traffic = json.load(open(tfp)).get(name, {}).get("bytes_per_launch")
-                tsrc = f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed; " \
-                       f"not measured in this run)"
-                break
+        tfp = os.path.join(ROOT, "profiles", f"pmc_summary_{wl}.json")
+        if os.path.exists(tfp):
+            rows = {k: v for k, v in json.load(open(tfp)).items() if k == name or k.startswith(name + "_")}
+            if len(rows) == 1:                        # one rocprof kernel class behind this bench kernel name
+                row = next(iter(rows.values()))
+                traffic = row.get("hbm_bytes_per_launch")
+                roof["mfma_busy_frac"] = row.get("mfma_busy_frac")
+                tsrc = (f"profiles/pmc_summary_{wl}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES "
+                        f"passes of this workload, tools/profile_round.sh, committed; not measured in this run)")
         roof.update({"kernel": name, "avg_launch_us": round(avg_ms * 1e3, 2), "launches": v["count"],
                      "alg_flops_per_launch": fl, "alg_bytes_per_launch": by, "traffic": traffic,
                      "traffic_source": tsrc})

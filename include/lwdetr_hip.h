@@ -168,6 +168,10 @@ int lwdetr_decoder_inputs(const void* enc_delta, const float* props_sel, const f
                           void* sine_out, void* xdec_out, int B, int nq, int d, int dtype, void* hip_stream);
 /* out[r] = (delta_xy * ref_wh + ref_xy, exp(delta_wh) * ref_wh) with ref row r % ref_rows (no sigmoid: bbox_reparam). */
 int lwdetr_box_reparam(const void* delta, const float* ref, long ref_rows, void* out, long R, int dtype, void* hip_stream);
+/* lwdetr_box_reparam into coord_out AND logits_out (R, ncls) contiguous = logits_pad (R rows, row stride ldc)[:, :ncls]: the
+ * user-visible pred_boxes / pred_logits of all decoder layers (models/lwdetr.py:150-173) in one launch. */
+int lwdetr_finalize_outputs(const void* delta, const float* ref, long ref_rows, void* coord_out, long R, const void* logits_pad,
+                            long ldc, int ncls, void* logits_out, int dtype, void* hip_stream);
 
 /* ---- sorted top-k (one workgroup per image) and its two users -----------------------------------------------------
  * Order: descending value, equal values by ascending index (torch.topk leaves tie order unspecified). N < 2^20, K <= 1024.
@@ -181,6 +185,10 @@ int lwdetr_rowmax(const void* x, long ld, long rows, int ncols, float* out, int 
 int lwdetr_topk(const void* x, int B, int N, int K, int64_t* idx_out, float* val_out, int dtype, void* hip_stream);
 int lwdetr_postprocess(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
                        float* scores, int64_t* labels, float* out_boxes, int dtype, void* hip_stream);
+/* Same selection, written as the (B, K, 6) f32 record of the detection all-gather: score, label, x0, y0, x1, y1
+ * (replaces the pickled per-image dicts of util/misc.py:99-139; labels < 2^24 are exact in f32). */
+int lwdetr_postprocess_packed(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
+                              float* packed, int dtype, void* hip_stream);
 
 /* ---- input side: uint8 HWC -> Pillow-exact bilinear square resize -> ToTensor -> Normalize -> NCHW --
  * Replaces datasets/transforms.py:223-231 (SquareResize = PIL.Image.resize((S,S), BILINEAR)), :437-443 (Normalize) and

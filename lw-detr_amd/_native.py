@@ -83,6 +83,8 @@ def lib():
         l.lwdetr_rowmax.argtypes = [vp, lg, lg, i, vp, i, vp]
         l.lwdetr_topk.argtypes = [vp, i, i, i, vp, vp, i, vp]
         l.lwdetr_postprocess.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp, i, vp]
+        l.lwdetr_postprocess_packed.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
+        l.lwdetr_finalize_outputs.argtypes = [vp, vp, lg, vp, lg, vp, lg, i, vp, i, vp]
         l.lwdetr_resize_normalize.argtypes = [vp, i, i, vp, vp, vp, vp, i, i, vp]
         l.lwdetr_prof_enable.argtypes = [i]
         l.lwdetr_prof_num_kernels.argtypes = []
@@ -91,7 +93,7 @@ def lib():
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
         for fn in ("lwdetr_msda_forward", "lwdetr_msda_backward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
                    "lwdetr_layernorm", "lwdetr_mlp_fused", "lwdetr_select_gather", "lwdetr_decoder_inputs",
-                   "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_resize_normalize", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
+                   "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_postprocess_packed", "lwdetr_finalize_outputs", "lwdetr_resize_normalize", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int
         _lib = l
     return _lib

@@ -654,6 +654,11 @@ __global__ __launch_bounds__(256) void gemm_apanel_kernel(const lwdetr_gemm_desc
 // 375 TFLOP/s with 64 x 64, 430 with 128 x 128). LDS swizzle for the 32-row fragments (lane -> row = lane & 31, 16-byte
 // k-slot 2 kc + (lane >> 5)): slot ^= (row >> 2) & 3 at KB = 32, (row >> 1) & 7 at KB = 64 - conflict-free for the 16-lane
 // ds_read_b128 service groups (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}).
+// Tuning builds (tools/gemm_big_variants.sh, -DLWDETR_BIG_VARIANT=bits): 1 = nt policy on the DMA, 2 = s_setprio(1) around
+// the MFMA groups, 4 = no sched_barrier between the read / DMA block and the MFMAs. The product is built with 0.
+#ifndef LWDETR_BIG_VARIANT
+#define LWDETR_BIG_VARIANT 0
+#endif
 template <typename T> struct Mma32;
 template <> struct Mma32<f16> {
     static __device__ __forceinline__ f32x16 k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -720,7 +725,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
                              (unsigned)(8 * (is_a ? k : k - A_MY) * 64 * EPC * (int)sizeof(T));
         const T* src = kt < nk ? psrc[k] + (long)kt * pstep[k] : zero;
         const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
+#if LWDETR_BIG_VARIANT & 1
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" :: "s"(m0v), "v"(src) : "memory");
+#else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
+#endif
     };
 
     int si = 0;
@@ -771,13 +780,21 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
                 }
 #pragma unroll
                 for (int k = c; k < PER_STAGE; k += KC) issue_piece(kt + NST - 1, k);   // refill the buffer stage kt - 1 used
+#if !(LWDETR_BIG_VARIANT & 4)
                 __builtin_amdgcn_sched_barrier(0);   // reads of chunk c + 1 and the DMA issue stay AHEAD of chunk c's MFMAs
+#endif
+#if LWDETR_BIG_VARIANT & 2
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)     // ROW: D[n][m], lane holds 4 consecutive n of one row m; COL: D[m][n]
                         acc[j][i] = COL ? Mma32<T>::k16(xf[c & 1][i], wf[c & 1][j], acc[j][i])
                                         : Mma32<T>::k16(wf[c & 1][j], xf[c & 1][i], acc[j][i]);
+#if LWDETR_BIG_VARIANT & 2
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
         }
         wait_vmcnt<0>();        // the dummy tail pieces (hipcc does not know about them)

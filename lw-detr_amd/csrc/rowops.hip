@@ -163,6 +163,27 @@ __global__ __launch_bounds__(256) void box_reparam_kernel(const T* __restrict__ 
     out[r * 4 + 3] = from_f32<T>(expf(d3) * rf[3]);
 }
 
+// final boxes of all decoder layers (box_reparam) AND the contiguous copy of their class logits out of the padded GEMM
+// output, in one launch: element i of the R x ncls logits block is copied by thread i, threads i < R also do row i's box
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_outputs_kernel(const T* __restrict__ delta, const float* __restrict__ ref, long ref_rows,
+                                                               T* __restrict__ coord, long R, const T* __restrict__ logits_pad,
+                                                               long ldc, int ncls, T* __restrict__ logits_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R * ncls) {
+        const long r = i / ncls;
+        logits_out[i] = logits_pad[r * ldc + (i - r * ncls)];
+    }
+    if (i < R) {
+        const float* rf = ref + (i % ref_rows) * 4;
+        const float d0 = to_f32<T>(delta[i * 4]), d1 = to_f32<T>(delta[i * 4 + 1]), d2 = to_f32<T>(delta[i * 4 + 2]), d3 = to_f32<T>(delta[i * 4 + 3]);
+        coord[i * 4] = from_f32<T>(d0 * rf[2] + rf[0]);
+        coord[i * 4 + 1] = from_f32<T>(d1 * rf[3] + rf[1]);
+        coord[i * 4 + 2] = from_f32<T>(expf(d2) * rf[2]);
+        coord[i * 4 + 3] = from_f32<T>(expf(d3) * rf[3]);
+    }
+}
+
 }  // namespace
 
 #define LWDETR_DISPATCH_T(dtype, CALL)                 \
@@ -205,5 +226,18 @@ extern "C" int lwdetr_box_reparam(const void* delta, const float* ref, long ref_
     ProfScope ps(KID_ELTWISE, 0.0, 0.0, st);
     LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((box_reparam_kernel<TT>), dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
                                                 (const TT*)delta, ref, ref_rows, (TT*)out, R));
+    return lwdetr_check_launch();
+}
+
+extern "C" int lwdetr_finalize_outputs(const void* delta, const float* ref, long ref_rows, void* coord_out, long R,
+                                       const void* logits_pad, long ldc, int ncls, void* logits_out, int dtype, void* hip_stream) {
+    if (!delta || !ref || !coord_out || !logits_pad || !logits_out || R < 0 || ref_rows <= 0 || ncls <= 0 || ldc < ncls) return LWDETR_ERR_BAD_ARG;
+    if (R == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_ELTWISE, 0.0, 0.0, st);
+    const long n = R * ncls;
+    LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((finalize_outputs_kernel<TT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                                (const TT*)delta, ref, ref_rows, (TT*)coord_out, R, (const TT*)logits_pad, ldc, ncls,
+                                                (TT*)logits_out));
     return lwdetr_check_launch();
 }

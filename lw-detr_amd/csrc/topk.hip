@@ -152,7 +152,7 @@ template <typename T, bool CACHE>
 __global__ __launch_bounds__(TK_THREADS) void postprocess_kernel(const T* __restrict__ logits, const T* __restrict__ boxes,
                                                                  const float* __restrict__ sizes, int nq, int ncls, int K,
                                                                  float* __restrict__ scores, int64_t* __restrict__ labels,
-                                                                 float* __restrict__ out_boxes) {
+                                                                 float* __restrict__ out_boxes, float* __restrict__ packed) {
     __shared__ TopkShared sh;
     extern __shared__ unsigned tk_keys[];
     const int b = blockIdx.x;
@@ -165,17 +165,22 @@ __global__ __launch_bounds__(TK_THREADS) void postprocess_kernel(const T* __rest
         const int i = (int)(TK_IDX_MASK - (unsigned)(c & TK_IDX_MASK));
         const int q = i / ncls;
         const float v = fkey_inv((unsigned)(c >> TK_IDX_BITS));
-        scores[o] = to_f32<T>(from_f32<T>(1.f / (1.f + expf(-v))));        // sigmoid evaluated in f32, stored at T's precision
-        labels[o] = (int64_t)(i - q * ncls);
+        const float score = to_f32<T>(from_f32<T>(1.f / (1.f + expf(-v))));   // sigmoid evaluated in f32, stored at T's precision
         const T* bx = boxes + ((long)b * nq + q) * 4;
         const float cx = to_f32<T>(bx[0]), cy = to_f32<T>(bx[1]);
         const float w = fmaxf(to_f32<T>(bx[2]), 0.f), h = fmaxf(to_f32<T>(bx[3]), 0.f);
         const float ih = sizes[b * 2], iw = sizes[b * 2 + 1];               // target_sizes rows are (h, w)
         // corners are formed at T's precision (the reference computes them on the model-dtype tensor) and scaled in f32
-        out_boxes[o * 4 + 0] = to_f32<T>(from_f32<T>(cx - 0.5f * w)) * iw;
-        out_boxes[o * 4 + 1] = to_f32<T>(from_f32<T>(cy - 0.5f * h)) * ih;
-        out_boxes[o * 4 + 2] = to_f32<T>(from_f32<T>(cx + 0.5f * w)) * iw;
-        out_boxes[o * 4 + 3] = to_f32<T>(from_f32<T>(cy + 0.5f * h)) * ih;
+        const float x0 = to_f32<T>(from_f32<T>(cx - 0.5f * w)) * iw, y0 = to_f32<T>(from_f32<T>(cy - 0.5f * h)) * ih;
+        const float x1 = to_f32<T>(from_f32<T>(cx + 0.5f * w)) * iw, y1 = to_f32<T>(from_f32<T>(cy + 0.5f * h)) * ih;
+        if (packed) {       // (B, K, 6) f32 rows: score, label, x0, y0, x1, y1 - the record the detection all-gather ships
+            float* pr = packed + o * 6;
+            pr[0] = score; pr[1] = (float)(i - q * ncls); pr[2] = x0; pr[3] = y0; pr[4] = x1; pr[5] = y1;
+        } else {
+            scores[o] = score;
+            labels[o] = (int64_t)(i - q * ncls);
+            out_boxes[o * 4 + 0] = x0; out_boxes[o * 4 + 1] = y0; out_boxes[o * 4 + 2] = x1; out_boxes[o * 4 + 3] = y1;
+        }
     }
 }
 
@@ -251,9 +256,9 @@ extern "C" int lwdetr_topk(const void* x, int B, int N, int K, int64_t* idx_out,
     return lwdetr_check_launch();
 }
 
-extern "C" int lwdetr_postprocess(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
-                                  float* scores, int64_t* labels, float* out_boxes, int dtype, void* hip_stream) {
-    if (!logits || !boxes || !target_sizes || !scores || !labels || !out_boxes || B < 0 || nq <= 0 || ncls <= 0 || K <= 0 ||
+static int postprocess_impl(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
+                                  float* scores, int64_t* labels, float* out_boxes, float* packed, int dtype, void* hip_stream) {
+    if (!logits || !boxes || !target_sizes || B < 0 || nq <= 0 || ncls <= 0 || K <= 0 ||
         K > TK_MAXK || (long)nq * ncls > (long)TK_IDX_MASK || K > nq * ncls)
         return LWDETR_ERR_BAD_ARG;
     if (B == 0) return LWDETR_OK;
@@ -265,11 +270,23 @@ extern "C" int lwdetr_postprocess(const void* logits, const void* boxes, const f
         if (cache) {
             if (!tk_allow_lds((const void*)postprocess_kernel<TT, true>)) return LWDETR_ERR_LAUNCH;
             hipLaunchKernelGGL((postprocess_kernel<TT, true>), dim3(B), dim3(TK_THREADS), kb, st, (const TT*)logits, (const TT*)boxes,
-                               target_sizes, nq, ncls, K, scores, labels, out_boxes);
+                               target_sizes, nq, ncls, K, scores, labels, out_boxes, packed);
         } else {
             hipLaunchKernelGGL((postprocess_kernel<TT, false>), dim3(B), dim3(TK_THREADS), 0, st, (const TT*)logits, (const TT*)boxes,
-                               target_sizes, nq, ncls, K, scores, labels, out_boxes);
+                               target_sizes, nq, ncls, K, scores, labels, out_boxes, packed);
         }
     });
     return lwdetr_check_launch();
+}
+
+extern "C" int lwdetr_postprocess(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls, int K,
+                                  float* scores, int64_t* labels, float* out_boxes, int dtype, void* hip_stream) {
+    if (!scores || !labels || !out_boxes) return LWDETR_ERR_BAD_ARG;
+    return postprocess_impl(logits, boxes, target_sizes, B, nq, ncls, K, scores, labels, out_boxes, nullptr, dtype, hip_stream);
+}
+
+extern "C" int lwdetr_postprocess_packed(const void* logits, const void* boxes, const float* target_sizes, int B, int nq, int ncls,
+                                         int K, float* packed, int dtype, void* hip_stream) {
+    if (!packed) return LWDETR_ERR_BAD_ARG;
+    return postprocess_impl(logits, boxes, target_sizes, B, nq, ncls, K, nullptr, nullptr, nullptr, packed, dtype, hip_stream);
 }

@@ -445,8 +445,9 @@ class ForwardPlan:
         self.op_dec_inputs = K.RawOp("lwdetr_decoder_inputs", (
             ptr(self.enc_delta), ptr(self.props_sel), ptr(self.refpoint), ptr(self.vr), L, ptr(self.query_feat),
             ptr(self.dim_t), ptr(self.enc_boxes), ptr(self.ref), ptr(self.sine), ptr(self.xdec), B, nq, d, code), keep=())
-        self.op_boxes = K.RawOp("lwdetr_box_reparam", (
-            ptr(self.delta), ptr(self.ref), B * nq, ptr(self.coord), nl * B * nq, code), keep=())
+        self.op_finalize = K.RawOp("lwdetr_finalize_outputs", (
+            ptr(self.delta), ptr(self.ref), B * nq, ptr(self.coord), nl * B * nq, ptr(self.logits), self.ldc, self.ncls,
+            ptr(self.logits), code), keep=())        # args 3 (boxes) and 8 (logits) are replaced by the call's output tensors
 
     # ------------------------------------------------------------------------------- per-call host-side glue
     def _masks(self, mask):
@@ -526,20 +527,24 @@ class ForwardPlan:
             self.op_topk(stream)
         else:
             self.topk_idx.copy_(forced_topk)
-        self.op_gather(stream)
+        # user-visible outputs are fresh tensors of this call, written directly by the kernels that produce them (no clone /
+        # slice-copy launches): encoder logits by the gather, encoder boxes by the decoder-input kernel, the decoder layers'
+        # boxes and the contiguous copy of their class logits (the GEMM output rows are padded to ldc) by one final launch
+        nl, ncls = self.cfg.dec_layers, self.ncls
+        empty = lambda *sh: torch.empty(*sh, dtype=T, device=self.dev)
+        enc_logits, enc_boxes = empty(B, nq, ncls), empty(B, nq, 4)
+        cls, coord = empty(nl, B, nq, ncls), empty(nl, B, nq, 4)
+        self.op_gather.call_with(stream, {6: enc_logits.data_ptr()})
         for op in self.ops_sel:
             op(stream)
-        self.op_dec_inputs(stream)
+        self.op_dec_inputs.call_with(stream, {7: enc_boxes.data_ptr()})
         for op in self.ops_dec:
             op(stream)
-        self.op_boxes(stream)
-        nl = self.cfg.dec_layers
-        cls = self.logits.view(nl, B, nq, self.ldc)[..., :self.ncls].clone()
-        coord = self.coord.clone()
+        self.op_finalize.call_with(stream, {3: coord.data_ptr(), 8: cls.data_ptr()})
         out = {"pred_logits": cls[-1], "pred_boxes": coord[-1]}
         if self.cfg.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(cls[:-1], coord[:-1])]
-        out["enc_outputs"] = {"pred_logits": self.enc_logits_sel.clone(), "pred_boxes": self.enc_boxes.clone()}
+        out["enc_outputs"] = {"pred_logits": enc_logits, "pred_boxes": enc_boxes}
         if collect is not None:
             if forced_topk is not None:
                 self.op_rowmax(stream)

@@ -206,6 +206,15 @@ class RawOp:
         if rc:
             _nat.check(rc, self.name)
 
+    def call_with(self, stream, repl):
+        """Launch with some positional arguments replaced ({index: value}) - per-call output pointers."""
+        args = list(self.args)
+        for i, v in repl.items():
+            args[i] = v
+        rc = self._fn(*args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, self.name)
+
 
 class MsdaFusedOp:
     def __init__(self, value, shapes, lsi, oa, ld_oa, logit_col, ref, vr, out, *, B, S, M, D, L, Q, P):

@@ -183,6 +183,26 @@ class PostProcess(nn.Module):
         xyxy = xyxy * torch.stack([img_w, img_h, img_w, img_h], dim=1)[:, None, :]
         return scores, labels, xyxy
 
+    def select_packed(self, logits, boxes, target_sizes):
+        """``select`` written as ONE (B, K, 6) f32 tensor of rows (score, label, x0, y0, x1, y1) - the record
+        ``lwdetr_amd.dist.all_gather_detections`` ships (same kernel, same values as ``dist.pack_detections(*select(...))``)."""
+        if not logits.is_cuda:
+            from ..dist import pack_detections
+            return pack_detections(*self.select(logits, boxes, target_sizes))
+        from .. import _native
+        b, nq, ncls = logits.shape
+        dev = logits.device
+        logits = logits.contiguous()
+        boxes = boxes.to(logits.dtype).contiguous()
+        sizes = target_sizes.to(device=dev, dtype=torch.float32).contiguous()
+        out = torch.empty(b, self.num_select, 6, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _native.lib().lwdetr_postprocess_packed(logits.data_ptr(), boxes.data_ptr(), sizes.data_ptr(), b, nq, ncls,
+                                                         self.num_select, out.data_ptr(), _native.dtype_code(logits.dtype),
+                                                         _native.stream_ptr(dev))
+        _native.check(rc, "lwdetr_postprocess_packed")
+        return out
+
     def _select_hip(self, logits, boxes, target_sizes, out=None):
         from .. import _native
         b, nq, ncls = logits.shape

@@ -107,12 +107,16 @@ def test_fp32_stages_match_oracle(name):
     assert (out["pred_boxes"].float().cpu() - exp["pred_boxes"]).abs().max().item() < 5e-4
 
 
-@pytest.mark.parametrize("name,dtype,tol_mem,tol_out", [("small_640", torch.float16, 0.05, 0.15),
-                                                         ("medium_640", torch.bfloat16, 0.3, 0.8),
-                                                         ("xlarge_960", torch.float16, 0.08, 0.25)])
-def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_out, mlp_path):
-    """fp16 / bf16 compute (BASELINE configs 2, 3, 5): compared with teacher-forced two-stage indices - slot-wise
-    comparison under a free top-k is meaningless at these precisions; the selected SET is checked."""
+# bounds <= 2x the values measured on MI355X (round 2): small fp16 0.0218 / 0.00176, medium bf16 0.130 / 0.0098, large fp16
+# 0.042 / 0.0037 (batch-32 run of tests/test_gpu_baseline_configs.py), xlarge 960 fp16 0.0471 / 0.0034 (logits / boxes)
+@pytest.mark.parametrize("name,dtype,tol_mem,tol_logit,tol_box", [("small_640", torch.float16, 0.05, 0.044, 0.0036),
+                                                                   ("medium_640", torch.bfloat16, 0.3, 0.26, 0.02),
+                                                                   ("large_640", torch.float16, 0.05, 0.083, 0.0074),
+                                                                   ("xlarge_960", torch.float16, 0.08, 0.094, 0.0069)])
+def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_logit, tol_box, mlp_path):
+    """fp16 / bf16 compute (BASELINE configs 2-5 at golden batch size): compared with teacher-forced two-stage indices -
+    slot-wise comparison under a free top-k is meaningless at these precisions (the k-th selected token is paired with the
+    k-th learned query, see tests/test_gpu_baseline_configs.py); the selected SET is checked."""
     g = load_golden(name)
     size, images, mask = case_batch(name)
     model, _ = _model(size, golden_state_dict(g), dtype)
@@ -120,11 +124,12 @@ def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_out, mlp_path):
     forced = torch.from_numpy(g["topk_idx"]).to(DEV)
     out = model(images.to(DEV), _collect=col, _forced_topk=forced)
     d = _diffs(out, g)
-    with open(os.path.join(ROOT, "gpurun_out", f"parity_{str(dtype).split('.')[-1]}_{name}.json"), "w") as f:
+    d["enc_class_max"] = float(np.abs(col["enc.class_max"].cpu().numpy() - g["enc_class_max"]).max())
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_{str(dtype).split('.')[-1]}_{name}_mlp{mlp_path}.json"), "w") as f:
         json.dump(d, f)
-    assert np.abs(col["enc.class_max"].cpu().numpy() - g["enc_class_max"]).max() < tol_mem
-    assert max(d["pred_logits"], d["enc_logits"]) < tol_out, d
-    assert max(d["pred_boxes"], d["enc_boxes"]) < tol_out * 0.2, d
+    assert d["enc_class_max"] < tol_mem
+    assert max(d["pred_logits"], d["enc_logits"]) < tol_logit, d
+    assert max(d["pred_boxes"], d["enc_boxes"]) < tol_box, d
     free = model(images.to(DEV), _collect=col)
     a, b = col["topk_idx"].cpu().numpy(), g["topk_idx"]
     overlap = np.mean([len(set(x) & set(y)) / len(y) for x, y in zip(a, b)])

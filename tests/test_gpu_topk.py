@@ -106,6 +106,10 @@ def test_postprocess_kernel_matches_tensor_ops(dtype, b_nq_c):
     assert (s.cpu() - es).abs().max().item() <= ulp
     assert torch.equal(l.cpu(), li % c)
     assert (bx.cpu() - exy).abs().max().item() <= ulp * 1300
+    # the packed form (the record of the detection all-gather) carries exactly the same values
+    from lwdetr_amd.dist import pack_detections
+    packed = post.select_packed(logits.to(DEV), boxes.to(DEV), sizes.to(DEV))
+    assert packed.shape == (b, k, 6) and torch.equal(packed, pack_detections(s, l, bx))
     # the module form returns the reference's list of dicts, scores in the logits' dtype
     res = post({"pred_logits": logits.to(DEV), "pred_boxes": boxes.to(DEV)}, sizes.to(DEV))
     assert len(res) == b and res[0]["scores"].dtype == dtype and res[0]["boxes"].shape == (k, 4)

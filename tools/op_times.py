@@ -43,7 +43,7 @@ def main():
     plan = model._plan(a.batch, a.res, a.res)
     stream = _native.stream_ptr(dev)
     groups = [("backbone", plan.ops_backbone), ("enc", plan.ops_enc), ("sel", [plan.op_rowmax, plan.op_topk, plan.op_gather] + list(plan.ops_sel) + [plan.op_dec_inputs]),
-              ("dec", list(plan.ops_dec) + [plan.op_boxes])]
+              ("dec", list(plan.ops_dec) + [plan.op_finalize])]
     total = 0.0
     for gname, ops in groups:
         for i, op in enumerate(ops):

@@ -1,24 +1,27 @@
 #!/bin/bash
-# Round profile on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh <tag>
-# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> gpurun_out/prof_<tag>/..._kernel_stats.csv
-# 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; counters are never combined with other trace domains)
-# 3. tools/pmc_summary.py reduces them to HBM bytes per launch per kernel -> gpurun_out/<tag>_hbm_traffic.json
+# Profile of one bench.py workload on the GPU box (run through gpurun from the repo root):
+#     bash tools/profile_round.sh <tag> [bench.py workload flags, e.g. --size medium --batch 64 --dtype bf16]
+# 1. rocprofv3 --kernel-trace --stats of the bench command            -> gpurun_out/keep_<tag>/<tag>_kernel_stats.csv
+# 2. separate --pmc passes (counters are never combined with other trace domains): FETCH_SIZE | WRITE_SIZE |
+#    MFMA busy + wave-cycle split | MFMA instruction counts + GRBM_GUI_ACTIVE | L2 hit / miss
+# 3. tools/pmc_summary.py reduces them to gpurun_out/keep_<tag>/<tag>_pmc_summary.json (HBM bytes per launch, MFMA busy
+#    fraction, wait split per kernel). Copy keep_<tag>/* to profiles/ to publish.
 set -u
-TAG=${1:-rX}
+TAG=${1:-rX}; shift || true
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
-mkdir -p "$OUT"
+KEEP=$OUT/keep_$TAG
+mkdir -p "$KEEP"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o small_b32_fp16 -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_${TAG}_bench.json" 2> "$OUT/prof_${TAG}_bench.err"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${TAG}_$c" -o b -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2> "$OUT/pmc_${TAG}_$c.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o p -- python "$ROOT/bench.py" --no-cpu-baseline "$@" > "$KEEP/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/prof_${TAG}_bench.err"
+find "$OUT/prof_$TAG" -name "*kernel_stats.csv" -exec cp {} "$KEEP/${TAG}_kernel_stats.csv" \;
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_${TAG}_$i" -o b -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline "$@" > /dev/null 2> "$OUT/pmc_${TAG}_$i.err"
 done
 cd "$ROOT"
-du -sh "$OUT"/prof_$TAG "$OUT"/pmc_${TAG}_* 2>/dev/null
-python tools/pmc_summary.py "$OUT/pmc_${TAG}_FETCH_SIZE" "$OUT/pmc_${TAG}_WRITE_SIZE" > "$OUT/${TAG}_hbm_traffic.json"
-# keep the summaries only (the raw traces exceed what gpurun copies back)
-mkdir -p "$OUT/keep_$TAG"
-find "$OUT/prof_$TAG" \( -name "*kernel_stats.csv" -o -name "*domain_stats.csv" \) -exec cp {} "$OUT/keep_$TAG/" \;
-rm -rf "$OUT/prof_$TAG" "$OUT"/pmc_${TAG}_FETCH_SIZE "$OUT"/pmc_${TAG}_WRITE_SIZE
-ls -la "$OUT/keep_$TAG"; tail -3 "$OUT/prof_${TAG}_bench.err"; tail -2 "$OUT"/pmc_${TAG}_FETCH_SIZE.err
+python tools/pmc_summary.py "$KEEP/${TAG}_kernel_stats.csv" "$OUT"/pmc_${TAG}_[1-5] > "$KEEP/${TAG}_pmc_summary.json"
+rm -rf "$OUT/prof_$TAG" "$OUT"/pmc_${TAG}_[1-5]
+ls -la "$KEEP"; tail -2 "$OUT/prof_${TAG}_bench.err"; tail -2 "$OUT"/pmc_${TAG}_1.err
