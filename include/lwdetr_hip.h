@@ -126,6 +126,8 @@ typedef struct {
     int keys_per_seq;   /* tokens (incl. pad rows) spanned by one sequence; >= 8 and a multiple of 4 */
     int sub_stride, sub_len; /* key j is real iff (j % sub_stride) < sub_len */
     int kind;           /* 0 window, 1 global, 2 decoder self-attention (profiling label only) */
+    int vt_slack;       /* nonzero: at least 8 readable bytes follow the VT tensor (lets the LDS-ring kernel serve sequences
+                           whose length is not a multiple of 8: it fetches V^T in whole 16-byte runs) */
 } lwdetr_attn_desc;
 
 int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* hip_stream);

@@ -50,7 +50,7 @@ class AttnDesc(C.Structure):
     _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("VT", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_long),
                 ("B", C.c_int), ("heads", C.c_int), ("hd", C.c_int), ("Tp", C.c_int), ("seqs_per_img", C.c_int),
                 ("seq_tok_stride", C.c_int), ("keys_per_seq", C.c_int), ("sub_stride", C.c_int),
-                ("sub_len", C.c_int), ("kind", C.c_int)]
+                ("sub_len", C.c_int), ("kind", C.c_int), ("vt_slack", C.c_int)]
 
 
 def is_built() -> bool:

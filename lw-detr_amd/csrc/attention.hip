@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
     const T* __restrict__ Vb = (const T*)p.VT + bh * HD * (long)p.Tp + tok0;
     const int q0 = qblk * QWG + wave * QW;
     const bool active = q0 < nkeys;                    // wave-uniform; idle waves still feed the ring and hit the barriers
-    const int nblk = nkeys / KB;                       // launcher guarantees nkeys % 64 == 0
+    const int nblk = (nkeys + KB - 1) / KB;            // a ragged last stage is masked in the softmax (keys >= nkeys)
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = m][16c + 8h .. + 7]
     V8 qf[QT][NC];
@@ -380,9 +380,15 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
     }
 
     // ---- DMA piece table of this wave: piece i = wave + j * NW of a stage (K pieces first, then V^T, then dummies)
-    const T* src0[PPW]; int sstep[PPW]; unsigned dst0[PPW]; bool real[PPW];
+    // Stages are whole 64-key blocks; in the LAST block of a ragged sequence the rows / 8-key runs past the sequence are
+    // not fetched through the block formula (they may lie outside the tensors): K lanes clamp to the last key, V^T lanes
+    // whose run starts at or past nkeys read the zero page. A run that straddles nkeys (nkeys % 8 == 4) is fetched whole -
+    // 8 bytes past the sequence, inside the V^T tensor except for its very last row: the caller guarantees that slack
+    // (lwdetr_attn_desc.vt_slack), otherwise such shapes stay on attn_kernel.
+    const T* src0[PPW]; const T* srct[PPW]; int sstep[PPW]; unsigned dst0[PPW]; bool real[PPW];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
     const unsigned dummy_dst = lds0 + NST * STAGE;
+    const int kt0 = (nblk - 1) * KB;                    // first key of the last block
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int i = wave + j * NW;
@@ -391,13 +397,16 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
             const int key = off / RB, slot = (off % RB) / 16;
             const int chunk = slot ^ ((key / RPB) & (CPR - 1));
             src0[j] = Kb + key * HD + chunk * 8; sstep[j] = KB * HD; dst0[j] = i * 1024; real[j] = true;
+            const int kc = kt0 + key < nkeys ? kt0 + key : nkeys - 1;
+            srct[j] = Kb + (long)kc * HD + chunk * 8;
         } else if (i < NP) {
             const int v = i - NKP;
             const int row = 8 * v + (lane >> 3), slot = lane & 7;
             const int chunk = slot ^ ((row >> 1) & 7);
             src0[j] = Vb + (long)row * p.Tp + chunk * 8; sstep[j] = KB; dst0[j] = KIMG + v * 1024; real[j] = true;
+            srct[j] = kt0 + chunk * 8 < nkeys ? src0[j] + kt0 : (const T*)g_attn_zero16;
         } else {
-            src0[j] = (const T*)g_attn_zero16; sstep[j] = 0; dst0[j] = 0; real[j] = false;
+            src0[j] = (const T*)g_attn_zero16; srct[j] = src0[j]; sstep[j] = 0; dst0[j] = 0; real[j] = false;
         }
     }
     auto issue = [&](int blk, int slot_) {             // always PPW pieces per wave: the wait counts are constants
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const bool live = real[j] && blk < nblk;    // wave-uniform
-            const T* src = live ? src0[j] + (long)blk * sstep[j] : (const T*)g_attn_zero16;
+            const T* src = !live ? (const T*)g_attn_zero16 : (blk == nblk - 1 ? srct[j] : src0[j] + (long)blk * sstep[j]);
             attn_dma16(src, __builtin_amdgcn_readfirstlane(live ? sb + dst0[j] : dummy_dst));
         }
     };
@@ -487,12 +496,14 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
                 }
                 // pad rows inside the sequence (960 x 960: 225 tokens in 228-row windows): register e <-> key
                 // k0 + 16 (e >> 3) + 8 h + (e & 7)
-                if (holes && res0 + 31 >= p.sub_len) {
+                const int k0 = kb * KB + t * 32;
+                if ((holes && res0 + 31 >= p.sub_len) || k0 + 32 > nkeys) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        int rr = res0 + 16 * (e >> 3) + 8 * h + (e & 7);
+                        const int ke = 16 * (e >> 3) + 8 * h + (e & 7);
+                        int rr = res0 + ke;
                         rr = rr >= p.sub_stride ? rr - p.sub_stride : rr;
-                        const bool ok = rr < p.sub_len;
+                        const bool ok = rr < p.sub_len && k0 + ke < nkeys;
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) sc[qt][e] = ok ? sc[qt][e] : -INFINITY;
                     }
@@ -616,8 +627,9 @@ template <typename T, int HD>
 int launch_lds_cfg(const lwdetr_attn_desc& p, hipStream_t st) {
     static const char* cfg = getenv("LWDETR_ATTN_LDS_CFG");
     int c = cfg ? atoi(cfg) : 0;
-    if (!c) c = HD >= 64 ? 208 : 108;
+    if (!c) c = p.keys_per_seq <= 128 ? 104 : (HD >= 64 && p.keys_per_seq >= 512 ? 208 : 108);   // a 100-key window = 4 waves of 32 queries
     switch (c) {
+        case 104: return launch_lds<T, HD, 1, 4>(p, st);
         case 108: return launch_lds<T, HD, 1, 8>(p, st);
         case 110: return launch_lds<T, HD, 1, 10>(p, st);
         case 204: return launch_lds<T, HD, 2, 4>(p, st);
@@ -638,11 +650,21 @@ template <int HD> struct LdsPath<bf16, HD> {
     static bool ok(const lwdetr_attn_desc& p) { return true; }
     static int go(const lwdetr_attn_desc& p, hipStream_t st) { return launch_lds_cfg<bf16, HD>(p, st); }
 };
+// Sequences the LDS-ring kernel takes: >= 64 keys (a ViT window or a whole image), 16-byte aligned K rows and outputs
+// (always), V^T runs that start on 8-byte boundaries (global_load_lds has dword alignment), masks with sub_stride >= 64.
+// A sequence length that is not a multiple of 8 makes the last 16-byte V^T run straddle the sequence end: taken only when
+// the caller vouches for 8 readable bytes after the V^T tensor (vt_slack). LWDETR_ATTN_LDS: 0 = never, 1 = long sequences
+// only (>= 512 keys), default (2) = also windows of >= 192 keys, 3 = everything >= 64 keys (tests).
 static bool lds_path_applies(const lwdetr_attn_desc& p) {
     static const char* force = getenv("LWDETR_ATTN_LDS");
-    if (force && atoi(force) == 0) return false;
-    return p.keys_per_seq >= 512 && p.keys_per_seq % 64 == 0 && p.seq_tok_stride % 8 == 0 && p.Tp % 8 == 0 &&
-           p.ldo % 8 == 0 && (p.sub_len == p.sub_stride || p.sub_stride >= 64);
+    const int mode = force ? atoi(force) : 2;
+    if (mode == 0) return false;
+    // measured (tools/attn_bench.py, us per launch, attn_kernel | LDS ring): 228-key windows hd64 B16: 240 | 131; 100-key windows
+    // hd16 B32: 36 | 54, hd32 B64: 113 | 124 - a 100-key sequence is over after two stages, the ring never pays for its start-up
+    if (p.keys_per_seq < (mode == 1 ? 512 : (mode == 3 ? 64 : 192))) return false;
+    if (p.keys_per_seq % 8 != 0 && !p.vt_slack) return false;
+    return p.keys_per_seq % 4 == 0 && p.seq_tok_stride % 4 == 0 && p.Tp % 4 == 0 && p.ldo % 8 == 0 &&
+           (p.sub_len == p.sub_stride || p.sub_stride >= 64);
 }
 
 template <typename T, int HD, int QT>

@@ -165,7 +165,9 @@ class ForwardPlan:
         self.x = z(rows, C)
         xn, att = z(rows, C), z(rows, C)
         hid = None if K.mlp_fused_supported(C, self.T, rows) else z(rows, 4 * C)
-        q, k, vt = z(B, heads, Tp, hd), z(B, heads, Tp, hd), z(B, heads, hd, Tp)
+        q, k = z(B, heads, Tp, hd), z(B, heads, Tp, hd)
+        self._vt_store = z(B * heads * hd * Tp + 8)          # 16 bytes of slack behind V^T (AttnDesc.vt_slack)
+        vt = self._vt_store[:B * heads * hd * Tp].view(B, heads, hd, Tp)
         ntap = len(self.taps)
         self.taps_cat = z(rows, ntap * C)
         pos = pw.custom(f"pos.{self.Hp}x{self.Wp}", lambda: abs_pos_winmajor(pw.sd[pre + ".pos_embed"].detach().cpu(),
@@ -191,7 +193,7 @@ class ForwardPlan:
             if window:
                 ops.append(AttnOp(q, k, vt, att, B=B, heads=heads, hd=hd, Tp=Tp, ldo=C, seqs_per_img=16,
                                   seq_tok_stride=self.Twp, keys_per_seq=self.Twp, sub_stride=self.Twp,
-                                  sub_len=self.Tw, kind=0))
+                                  sub_len=self.Tw, kind=0, vt_slack=True))
             else:
                 ops.append(AttnOp(q, k, vt, att, B=B, heads=heads, hd=hd, Tp=Tp, ldo=C, seqs_per_img=1,
                                   seq_tok_stride=Tp, keys_per_seq=Tp, sub_stride=self.Twp, sub_len=self.Tw, kind=1))

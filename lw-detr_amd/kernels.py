@@ -87,12 +87,13 @@ class GemmOp:
 
 class AttnOp:
     def __init__(self, Q, K, VT, out, *, B, heads, hd, Tp, ldo, seqs_per_img, seq_tok_stride, keys_per_seq,
-                 sub_stride, sub_len, kind):
+                 sub_stride, sub_len, kind, vt_slack=False):
         d = AttnDesc()
         d.Q, d.K, d.VT, d.out, d.ldo = _ptr(Q), _ptr(K), _ptr(VT), _ptr(out), ldo
         d.B, d.heads, d.hd, d.Tp = B, heads, hd, Tp
         d.seqs_per_img, d.seq_tok_stride, d.keys_per_seq = seqs_per_img, seq_tok_stride, keys_per_seq
         d.sub_stride, d.sub_len, d.kind = sub_stride, sub_len, kind
+        d.vt_slack = 1 if vt_slack else 0
         self.desc, self.dtype = d, _nat.dtype_code(Q.dtype)
         self._keep = (Q, K, VT, out)
         self._fn = _nat.lib().lwdetr_attention

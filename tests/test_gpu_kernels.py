@@ -167,7 +167,8 @@ def _attn_ref(q, k, v, valid):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("hd", [16, 32, 64])
-@pytest.mark.parametrize("geom", ["window100", "global1600", "holes", "decoder300", "holes3648", "global704"])
+@pytest.mark.parametrize("geom", ["window100", "global1600", "holes", "decoder300", "holes3648", "global704", "window100_slack",
+                                  "window228_slack"])
 def test_attention(dtype, hd, geom):
     from lwdetr_amd import kernels as K
     heads, b = 3, 2
@@ -175,7 +176,9 @@ def test_attention(dtype, hd, geom):
         twp, tw, spi, b, heads = 228, 225, 1, 1, 2
     elif geom == "global704":      # 11 x 64 keys: partially filled last workgroup of the LDS-ring kernel
         twp, tw, spi = 44, 44, 1
-    elif geom == "window100":
+    elif geom == "window228_slack":  # 960x960 windows (225 tokens in 228 rows) on the LDS-ring kernel (ragged last stage)
+        twp, tw, spi, b, heads = 228, 225, 16, 1, 2
+    elif geom in ("window100", "window100_slack"):
         twp, tw, spi = 100, 100, 16
     elif geom == "global1600":
         twp, tw, spi = 100, 100, 1
@@ -194,9 +197,13 @@ def test_attention(dtype, hd, geom):
     qs = (q.float() * scale).to(dtype)
     out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())
     keys = twp if spi == 16 else tp
-    K.AttnOp(qs, k, v.transpose(2, 3).contiguous(), out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd,
+    slack = geom.endswith("_slack")             # V^T with 16 readable bytes behind it: lets the LDS-ring kernel take windows
+    vt_store = torch.zeros(v.numel() + 8, dtype=dtype, device=_dev())
+    vt = vt_store[:v.numel()].view(b, heads, hd, tp)
+    vt.copy_(v.transpose(2, 3))
+    K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd,
              seqs_per_img=spi, seq_tok_stride=twp if spi == 16 else tp, keys_per_seq=keys, sub_stride=twp,
-             sub_len=tw, kind=0)()
+             sub_len=tw, kind=0, vt_slack=slack)()
     o = out.reshape(b, tp, heads, hd).permute(0, 2, 1, 3).float()
     qn = qs.float() / math.log2(math.e)      # kernel works in the log2 domain
     valid = (torch.arange(tp, device=_dev()) % twp) < tw

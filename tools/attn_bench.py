@@ -15,6 +15,10 @@ SHAPES = {  # name: (B, heads, hd, twp, tw, dtype)
     "large_b32_f16": (32, 12, 32, 100, 100, "float16"),
     "xlarge960_b16_f16": (16, 12, 64, 228, 225, "float16"),
     "small_b1_f16": (1, 12, 16, 100, 100, "float16"),
+    # window attention (16 sequences per image): name suffix _win
+    "small_b32_f16_win": (32, 12, 16, 100, 100, "float16"),
+    "medium_b64_bf16_win": (64, 12, 32, 100, 100, "bfloat16"),
+    "xlarge960_b16_f16_win": (16, 12, 64, 228, 225, "float16"),
 }
 VARIANTS = [("attn_kernel", {"LWDETR_ATTN_LDS": "0"}), ("lds 1x8", {"LWDETR_ATTN_LDS_CFG": "108"}),
             ("lds 1x10", {"LWDETR_ATTN_LDS_CFG": "110"}), ("lds 2x4", {"LWDETR_ATTN_LDS_CFG": "204"}),
@@ -30,10 +34,14 @@ def child(shape):
     g = torch.Generator(device="cpu").manual_seed(0)
     q = (torch.randn(B, heads, Tp, hd, generator=g) * 0.5).to(dev).to(T)
     k = torch.randn(B, heads, Tp, hd, generator=g).to(dev).to(T)
-    vt = torch.randn(B, heads, hd, Tp, generator=g).to(dev).to(T)
+    store = torch.zeros(B * heads * hd * Tp + 8, device=dev, dtype=T)
+    vt = store[:B * heads * hd * Tp].view(B, heads, hd, Tp)
+    vt.copy_(torch.randn(B, heads, hd, Tp, generator=g).to(T))
     out = torch.zeros(B * Tp, heads * hd, device=dev, dtype=T)
-    op = K.AttnOp(q, k, vt, out, B=B, heads=heads, hd=hd, Tp=Tp, ldo=heads * hd, seqs_per_img=1, seq_tok_stride=Tp,
-                  keys_per_seq=Tp, sub_stride=twp, sub_len=tw, kind=1)
+    win = shape.endswith("_win")
+    op = K.AttnOp(q, k, vt, out, B=B, heads=heads, hd=hd, Tp=Tp, ldo=heads * hd, seqs_per_img=16 if win else 1,
+                  seq_tok_stride=twp if win else Tp, keys_per_seq=twp if win else Tp, sub_stride=twp, sub_len=tw,
+                  kind=0 if win else 1, vt_slack=True)
     for _ in range(3):
         op()
     ts = []
@@ -42,7 +50,7 @@ def child(shape):
         e0.record(); op(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
-    flops = 4.0 * B * heads * Tp * Tp * hd
+    flops = 4.0 * B * heads * Tp * (twp if win else Tp) * hd
     med = ts[len(ts) // 2]
     print(f"{med:9.1f} us (min {ts[0]:.1f})  {flops / med / 1e6:7.1f} TFLOP/s", flush=True)
 
