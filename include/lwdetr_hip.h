@@ -131,6 +131,9 @@ typedef struct {
 } lwdetr_attn_desc;
 
 int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* hip_stream);
+/* Kernel selection override for tests / tuning (process-wide): lds_mode -1 = default (environment LWDETR_ATTN_LDS, else 2),
+ * 0 = never use the LDS-ring kernel, 1 = sequences of >= 512 keys, 2 = also >= 192-key windows, 3 = everything >= 64 keys. */
+void lwdetr_attention_tuning(int lds_mode);
 
 /* ---- row LayerNorm: out[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta; biased variance; C % 4 == 0 ------------- */
 /* rows_per_batch / out_batch_stride / out_row_offset let the projector write straight into `memory` (B,S,d). */

@@ -74,6 +74,8 @@ def lib():
         l.lwdetr_attention.argtypes = [C.POINTER(AttnDesc), i, vp]
         l.lwdetr_gemm_tuning.argtypes = [i]
         l.lwdetr_gemm_tuning.restype = None
+        l.lwdetr_attention_tuning.argtypes = [i]
+        l.lwdetr_attention_tuning.restype = None
         l.lwdetr_layernorm.argtypes = [vp, lg, vp, vp, vp, lg, lg, i, f, lg, lg, lg, i, vp]
         l.lwdetr_mlp_fused.argtypes = [vp, lg, vp, vp, vp, vp, vp, vp, lg, vp, lg, i, f, f, vp, lg, vp, vp, vp,
                                        vp, vp, vp, vp, vp, f, i, i, i, i, vp]

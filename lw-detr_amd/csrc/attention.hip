@@ -655,9 +655,10 @@ template <int HD> struct LdsPath<bf16, HD> {
 // A sequence length that is not a multiple of 8 makes the last 16-byte V^T run straddle the sequence end: taken only when
 // the caller vouches for 8 readable bytes after the V^T tensor (vt_slack). LWDETR_ATTN_LDS: 0 = never, 1 = long sequences
 // only (>= 512 keys), default (2) = also windows of >= 192 keys, 3 = everything >= 64 keys (tests).
+int g_attn_lds_mode = -1;        // lwdetr_attention_tuning(): overrides the environment / default (tests)
 static bool lds_path_applies(const lwdetr_attn_desc& p) {
     static const char* force = getenv("LWDETR_ATTN_LDS");
-    const int mode = force ? atoi(force) : 2;
+    const int mode = g_attn_lds_mode >= 0 ? g_attn_lds_mode : (force ? atoi(force) : 2);
     if (mode == 0) return false;
     // measured (tools/attn_bench.py, us per launch, attn_kernel | LDS ring): 228-key windows hd64 B16: 240 | 131; 100-key windows
     // hd16 B32: 36 | 54, hd32 B64: 113 | 124 - a 100-key sequence is over after two stages, the ring never pays for its start-up
@@ -705,6 +706,8 @@ int dispatch_hd(const lwdetr_attn_desc& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" void lwdetr_attention_tuning(int lds_mode) { g_attn_lds_mode = lds_mode; }
 
 extern "C" int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* hip_stream) {
     if (!desc) return LWDETR_ERR_BAD_ARG;

@@ -201,9 +201,14 @@ def test_attention(dtype, hd, geom):
     vt_store = torch.zeros(v.numel() + 8, dtype=dtype, device=_dev())
     vt = vt_store[:v.numel()].view(b, heads, hd, tp)
     vt.copy_(v.transpose(2, 3))
-    K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd,
-             seqs_per_img=spi, seq_tok_stride=twp if spi == 16 else tp, keys_per_seq=keys, sub_stride=twp,
-             sub_len=tw, kind=0, vt_slack=slack)()
+    from lwdetr_amd import _native
+    _native.lib().lwdetr_attention_tuning(3 if slack else -1)        # _slack cases: LDS-ring kernel for every length >= 64
+    try:
+        K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd,
+                 seqs_per_img=spi, seq_tok_stride=twp if spi == 16 else tp, keys_per_seq=keys, sub_stride=twp,
+                 sub_len=tw, kind=0, vt_slack=slack)()
+    finally:
+        _native.lib().lwdetr_attention_tuning(-1)
     o = out.reshape(b, tp, heads, hd).permute(0, 2, 1, 3).float()
     qn = qs.float() / math.log2(math.e)      # kernel works in the log2 domain
     valid = (torch.arange(tp, device=_dev()) % twp) < tw
