@@ -34,6 +34,10 @@ DEF(k_pkmulf16, "v_pk_mul_f16 %0, %0, %8\n v_pk_mul_f16 %1, %1, %8\n v_pk_mul_f1
 DEF(k_pkfmaf16, "v_pk_fma_f16 %0, %0, %8, %8\n v_pk_fma_f16 %1, %1, %8, %8\n v_pk_fma_f16 %2, %2, %8, %8\n v_pk_fma_f16 %3, %3, %8, %8\n v_pk_fma_f16 %4, %4, %8, %8\n v_pk_fma_f16 %5, %5, %8, %8\n v_pk_fma_f16 %6, %6, %8, %8\n v_pk_fma_f16 %7, %7, %8, %8\n")
 DEF(k_or3, "v_or3_b32 %0, %0, %1, %8\n v_or3_b32 %1, %1, %2, %8\n v_or3_b32 %2, %2, %3, %8\n v_or3_b32 %3, %3, %4, %8\n v_or3_b32 %4, %4, %5, %8\n v_or3_b32 %5, %5, %6, %8\n v_or3_b32 %6, %6, %7, %8\n v_or3_b32 %7, %7, %0, %8\n")
 DEF(k_swap32, "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n v_permlane32_swap_b32 %1, %2\n v_permlane32_swap_b32 %3, %4\n v_permlane32_swap_b32 %5, %6\n v_permlane32_swap_b32 %7, %0\n")
+DEF(k_pkrtz, "v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %1, %1, %2\n v_cvt_pkrtz_f16_f32 %2, %2, %3\n v_cvt_pkrtz_f16_f32 %3, %3, %4\n v_cvt_pkrtz_f16_f32 %4, %4, %5\n v_cvt_pkrtz_f16_f32 %5, %5, %6\n v_cvt_pkrtz_f16_f32 %6, %6, %7\n v_cvt_pkrtz_f16_f32 %7, %7, %0\n")
+DEF(k_max2, "v_max_f32 %0, %0, %1\n v_max_f32 %1, %1, %2\n v_max_f32 %2, %2, %3\n v_max_f32 %3, %3, %4\n v_max_f32 %4, %4, %5\n v_max_f32 %5, %5, %6\n v_max_f32 %6, %6, %7\n v_max_f32 %7, %7, %0\n")
+DEF(k_or2, "v_or_b32 %0, %0, %1\n v_or_b32 %1, %1, %2\n v_or_b32 %2, %2, %3\n v_or_b32 %3, %3, %4\n v_or_b32 %4, %4, %5\n v_or_b32 %5, %5, %6\n v_or_b32 %6, %6, %7\n v_or_b32 %7, %7, %0\n")
+DEF(k_sub, "v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n")
 DEF(k_ldexp, "v_ldexp_f32 %0, %0, %8\n v_ldexp_f32 %1, %1, %8\n v_ldexp_f32 %2, %2, %8\n v_ldexp_f32 %3, %3, %8\n v_ldexp_f32 %4, %4, %8\n v_ldexp_f32 %5, %5, %8\n v_ldexp_f32 %6, %6, %8\n v_ldexp_f32 %7, %7, %8\n")
 
 typedef void (*kfn)(float*, unsigned long long*, int);
@@ -59,5 +63,6 @@ int main() {
     run("v_fma_f32", k_fma); run("v_max3_f32", k_max3); run("v_cvt_pk_f16_f32", k_cvtpk); run("v_cvt_pk_bf16_f32", k_cvtpkbf);
     run("v_dot2c_f32_f16", k_dot2c); run("v_pk_mul_f16", k_pkmulf16); run("v_pk_fma_f16", k_pkfmaf16); run("v_or3_b32", k_or3);
     run("v_permlane32_swap", k_swap32); run("v_ldexp_f32", k_ldexp);
+    run("v_cvt_pkrtz_f16_f32", k_pkrtz); run("v_max_f32", k_max2); run("v_or_b32", k_or2); run("v_sub_f32", k_sub);
     return 0;
 }
