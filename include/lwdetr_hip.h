@@ -141,6 +141,12 @@ int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* b
                      int C, float eps, long rows_per_batch, long out_batch_rows, long out_row_offset, int dtype,
                      void* hip_stream);
 
+/* out1 = LN1(x), out2 = LN2(out1) in one pass over the row; bit-identical to two lwdetr_layernorm launches (the second reading
+ * out1). Decoder layer tail: norm3 followed by the shared decoder.norm (models/transformer.py:397-400, :466-517). */
+int lwdetr_layernorm_chain(const void* x, long ldx, const float* gamma1, const float* beta1, float eps1, void* out1, long ldo1,
+                           const float* gamma2, const float* beta2, float eps2, void* out2, long ldo2, long M, int C,
+                           int dtype, void* hip_stream);
+
 /* ---- fused ViT MLP: x <- x + gamma2 * fc2(GELU(fc1(LN(x)))), one launch, hidden activation stays on chip ---------
  * Replaces models/backbone/vit.py:217-218 (norm2 -> timm Mlp -> gamma_2 -> residual). Weight packing (host, once):
  *   w1_folded (4C, C) = fc1.weight * norm2.weight[None, :],  b1_folded = fc1.bias + fc1.weight @ norm2.bias (f32),

@@ -84,11 +84,11 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
         if (!col_orient) {
             // thread -> fixed 8-column run (col), rows strided by 256 / CPRW: column parameters are loop invariant and
             // fetched with two 16-byte loads each (bias / gamma buffers are padded to a multiple of 8 floats by the host)
-            constexpr int CPRW = BN / 8, RSTEP = NTHR / CPRW;
+            constexpr int CPRW = BN / 8, RSTEP = NTHR / CPRW;       // threads per row, rows per sweep (floor: BN = 192 leaves 8 idle)
             T* __restrict__ out2 = (T*)sg.out2;
             const T* __restrict__ res = (const T*)sg.res;
             const int col = (tid % CPRW) * 8, n = n0 + col;
-            if (n < n_end) {
+            if (n < n_end && tid < RSTEP * CPRW) {
                 const int nl = n - sg.n_begin, cnt = n_end - n < 8 ? n_end - n : 8;
                 float bv[8], gv[8];
 #pragma unroll
@@ -107,11 +107,11 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                 const int act = sg.act;
                 const float scale = sg.scale;
 #pragma unroll
-                for (int it = 0; it < 64 / RSTEP; ++it) {
+                for (int it = 0; it < (64 + RSTEP - 1) / RSTEP; ++it) {
                     const int row = tid / CPRW + it * RSTEP;
                     const long m = mbase + row;
                     long roff;
-                    if (m >= d.M || !row_offset(sg, m, roff)) continue;
+                    if (row >= 64 || m >= d.M || !row_offset(sg, m, roff)) continue;
                     bool keep_acc = true, keep_out = true;
                     if (sg.rowmask) {
                         const bool rm = sg.rowmask[m] != 0;
@@ -667,12 +667,13 @@ template <> struct Mma32<bf16> {
     static __device__ __forceinline__ f32x16 k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
-template <typename T, int BN, int KB, int NST>
+template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int BM = 256, EPC = 8;
-    constexpr int WGN = BN / 64, WGM = 8 / WGN;                   // wave grid: columns of 64, rows of BM / WGM
-    constexpr int WM = BM / WGM, WN = 64, TM = WM / 32, TN = WN / 32;
+    constexpr int WGN = BN == 256 ? 4 : 2, WGM = 8 / WGN;         // wave grid: 2 x 4 (BN 256) or 4 x 2 (BN 192 / 128)
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    static_assert(WN % 32 == 0 && (BN / (64 / (KB / 8))) % 8 == 0, "tile / stage combination not supported");
     constexpr int SLOTS = KB / EPC, RP = 64 / SLOTS, KC = KB / 16;
     constexpr int A_MY = BM / RP / 8, B_MY = BN / RP / 8, PER_STAGE = A_MY + B_MY;
     constexpr int STAGE = (BM + BN) * KB;                         // elements
@@ -705,12 +706,26 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
     const int prow = lane / SLOTS, pslot = lane % SLOTS;
     auto key_of = [](int row) { return KB == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
     const T* psrc[PER_STAGE]; int pstep[PER_STAGE];
+    // implicit-GEMM 3x3 view (AMODE CONV3x3): A row = output pixel (b, y, x); stage k0 reads channels k0 % Cin .. of the input
+    // pixel (y s + tap / 3 - 1, x s + tap % 3 - 1), tap = k0 / Cin (zero page outside the image). The shifted source row
+    // only changes with the tap - every Cin / KB stages - so its address is cached per piece (gemm_dma_kernel does the same).
+    int cv_b[A_MY], cv_y[A_MY], cv_x[A_MY], cv_tap[A_MY]; const T* cv_src[A_MY];
 #pragma unroll
     for (int k = 0; k < PER_STAGE; ++k) {
         const bool is_a = k < A_MY;
         const int row = RP * (wave + 8 * (is_a ? k : k - A_MY)) + prow;
         const long gr = (is_a ? m0 : (long)n0) + row;
         const bool ok = gr < (is_a ? d.M : (long)d.N);
+        if (AMODE == LWDETR_A_CONV3x3 && is_a) {
+            const int hw = d.conv_hout * d.conv_wout;
+            const int b = (int)(gr / hw), r = (int)(gr - (long)b * hw);
+            if (k < A_MY) {
+                cv_b[k < A_MY ? k : 0] = ok ? b : -1; cv_y[k < A_MY ? k : 0] = r / d.conv_wout;
+                cv_x[k < A_MY ? k : 0] = r - (r / d.conv_wout) * d.conv_wout; cv_tap[k < A_MY ? k : 0] = -1; cv_src[k < A_MY ? k : 0] = nullptr;
+            }
+            psrc[k] = zero + (pslot ^ key_of(row)) * 0; pstep[k] = (pslot ^ key_of(row)) * EPC;      // pstep: this lane's channel offset
+            continue;
+        }
         const T* base = is_a ? A + gr * d.lda : W + gr * (long)d.K;
         psrc[k] = ok ? base + (pslot ^ key_of(row)) * EPC : zero;
         pstep[k] = ok ? KB : 0;
@@ -723,7 +738,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
         const bool is_a = k < A_MY;
         const unsigned dst = lds0 + (unsigned)((kt % NST) * STAGE + (is_a ? 0 : BM * KB)) * (unsigned)sizeof(T) + wave_off +
                              (unsigned)(8 * (is_a ? k : k - A_MY) * 64 * EPC * (int)sizeof(T));
-        const T* src = kt < nk ? psrc[k] + (long)kt * pstep[k] : zero;
+        const T* src;
+        if (AMODE == LWDETR_A_CONV3x3 && is_a) {
+            const int kk = k < A_MY ? k : 0;
+            const int k0 = kt * KB, tap = k0 / d.conv_cin;               // wave-uniform
+            if (tap != cv_tap[kk]) {
+                cv_tap[kk] = tap;
+                const int iy = cv_y[kk] * d.conv_stride + tap / 3 - 1, ix = cv_x[kk] * d.conv_stride + tap % 3 - 1;
+                cv_src[kk] = (cv_b[kk] >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp)
+                                 ? A + tok_encode(cv_b[kk], iy, ix, d.a_tok) * d.lda + d.a_col0 + pstep[k] : nullptr;
+            }
+            src = (kt < nk && cv_src[kk]) ? cv_src[kk] + (k0 - tap * d.conv_cin) : zero;
+        } else {
+            src = kt < nk ? psrc[k] + (long)kt * pstep[k] : zero;
+        }
         const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
 #if LWDETR_BIG_VARIANT & 1
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" :: "s"(m0v), "v"(src) : "memory");
@@ -827,45 +855,52 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
     else body(std::false_type{});
 }
 
-template <typename T, int BN, int KB, int NST>
+template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
 int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     constexpr size_t ring = (size_t)NST * (256 + BN) * KB * sizeof(T);
     constexpr size_t stg = (size_t)(64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
     constexpr size_t lds = ring > stg ? ring : stg;
     static bool done = false;
     if (!done) {
-        if (hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
         done = true;
     }
     const long nwg = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST>), dim3((unsigned)nwg), dim3(512), lds, st, d);
+    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(512), lds, st, d);
     return lwdetr_check_launch();
 }
 
-// Shapes the large-tile kernel takes: plain A, no A2, K a multiple of 64, segment boundaries on the column tile, and (mode 1,
-// the default) enough work for 256-row tiles to fill the chip. LWDETR_GEMM_BIG / lwdetr_gemm_tuning(): 0 = never, 1 = default
-// thresholds, 2 = whenever legal (tests), 32 / 64 = whenever legal with that stage depth (tuning).
+// Shapes the large-tile kernel takes: plain A or the implicit-GEMM 3x3 view, no A2, K (and Cin) a multiple of 64, segment
+// boundaries on the column tile, and (mode 1, the default) enough work for 256-row tiles. Measured crossover (tools/op_times.py --gemm-big 2, M = 9600 .. 217600): K >= 384
+// wins from M = 16384 rows; with K >= 960 already from ~100 tiles (M = 9600 .. 12800, N = 384); short-K / few-tile shapes
+// (M = 9600: N 256 K 256 11 -> 25 us, N 2048 K 256 35 -> 49, N 256 K 2048 33 -> 70 on 38 tiles) stay on the 64 x 64 ring.
+// LWDETR_GEMM_BIG / lwdetr_gemm_tuning(): 0 = never, 1 = default thresholds, 2 = whenever legal (tests), 32 / 64 = whenever
+// legal with that stage depth (tuning).
 int g_big_mode = -1;
-template <typename T>
+template <typename T, int AMODE>
 int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
     taken = false;
-    if constexpr (sizeof(T) != 2) return LWDETR_OK;
+    if constexpr (sizeof(T) != 2 || AMODE == LWDETR_A_PATCH16) return LWDETR_OK;
     else {
         static const char* env = getenv("LWDETR_GEMM_BIG");
         const int mode = g_big_mode >= 0 ? g_big_mode : (env ? atoi(env) : 1);
-        if (!mode || d.a_mode != LWDETR_A_PLAIN || d.A2 || d.K % 64 != 0) return LWDETR_OK;
-        if (mode == 1 && (d.K < 384 || d.M < 16384 || d.N < 256)) return LWDETR_OK;       // measured crossover: see launch()
-        bool bn256 = d.N % 256 == 0 || d.N > 512;
-        for (int s = 0; s < d.nseg; ++s) {
-            if (d.seg[s].n_begin % 128 != 0) return LWDETR_OK;
-            if (d.seg[s].n_begin % 256 != 0) bn256 = false;
-        }
-        if (d.N < 128) return LWDETR_OK;
+        if (!mode || d.A2 || d.K % 64 != 0 || d.N < 128) return LWDETR_OK;
+        if (AMODE == LWDETR_A_CONV3x3 && (d.conv_cin % 64 != 0 || d.a_col0 % 8 != 0)) return LWDETR_OK;
+        // column tile: 256 where N and the segment boundaries allow; 192 for N <= 192 (the 3x3 convolutions of the C2f blocks:
+        // ONE column tile instead of two half-empty 128-wide ones); else 128. (Measured: N = 384 as 2 x 192 is 5-20 % slower
+        // than 3 x 128 - fewer, fatter tiles on a 2-deep ring - and N = 1152 ties.)
+        int bn = d.N % 256 == 0 || d.N > 512 ? 256 : (d.N <= 192 ? 192 : 128);
+        for (int s = 0; s < d.nseg; ++s)
+            if (d.seg[s].n_begin % bn != 0) bn = 128;
+        for (int s = 0; s < d.nseg; ++s) if (d.seg[s].n_begin % bn != 0) return LWDETR_OK;
+        const long tiles = ((d.M + 255) / 256) * ((d.N + bn - 1) / bn);
+        if (mode == 1 && !(d.K >= 384 && d.N >= 192 && (d.M >= 16384 || (d.K >= 960 && tiles >= 96)))) return LWDETR_OK;
         taken = true;
         const int variant = mode >= 10 ? mode : 0;     // tuning: 32 / 64 = stage depth (ring 4 / 2 deep)
-        if (bn256) return variant == 32 ? launch_big<T, 256, 32, 4>(d, st) : launch_big<T, 256, 64, 2>(d, st);
-        return variant == 32 ? launch_big<T, 128, 32, 4>(d, st) : launch_big<T, 128, 64, 3>(d, st);
+        if (bn == 256) return variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st);
+        if (bn == 192) return launch_big<T, 192, 64, 2, AMODE>(d, st);
+        return variant == 32 ? launch_big<T, 128, 32, 4, AMODE>(d, st) : launch_big<T, 128, 64, 3, AMODE>(d, st);
     }
 }
 
@@ -898,9 +933,9 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     if (nwg <= 0 || nwg > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
     const int kid = AMODE == LWDETR_A_PLAIN ? KID_GEMM : (AMODE == LWDETR_A_CONV3x3 ? KID_GEMM_CONV : KID_GEMM_PATCH);
     ProfScope ps(kid, 2.0 * d.M * d.N * d.K, ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) * sizeof(T), st);
-    if constexpr (AMODE == LWDETR_A_PLAIN) {
+    {
         bool taken = false;
-        const int rc = try_launch_big<T>(d, st, taken);
+        const int rc = try_launch_big<T, AMODE>(d, st, taken);
         if (taken) return rc;
     }
     if constexpr (sizeof(T) == 2) {

@@ -7,11 +7,16 @@ namespace {
 
 constexpr int LN_MAX_CHUNKS = 16;   // per lane: supports C <= 16 lanes * 16 chunks * EPC (2048 for 16-bit, 1024 for f32)
 
+// Optional chained second LayerNorm (gamma2 != nullptr): out2 = LN2(out) computed on the values just rounded to T, i.e.
+// bit-identical to a second launch reading `out` (decoder: norm3 followed by the shared decoder.norm, transformer.py:466-517,
+// :397-400) - one pass over the row instead of two launches.
 template <typename T, int NCH>   // NCH = 16-byte chunks held per lane (register resident row)
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, long ldo,
                                                         long M, int C, float eps, long rows_per_batch,
-                                                        long out_batch_rows, long out_row_offset) {
+                                                        long out_batch_rows, long out_row_offset,
+                                                        const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                        T* __restrict__ out2, long ldo2, float eps2) {
     constexpr int EPC = 16 / (int)sizeof(T);
     typedef T VC __attribute__((ext_vector_type(EPC)));
     const int lane16 = threadIdx.x & 15;
@@ -60,20 +65,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
             for (int e = 0; e < EPC; ++e)
                 t[e] = from_f32<T>((v[i][e] - mean) * rstd * gamma[c * EPC + e] + beta[c * EPC + e]);
             *(VC*)(outr + c * EPC) = t;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[i][e] = to_f32<T>(t[e]);
+        }
+    }
+    if (!gamma2) return;
+    float sum2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane16 + 16 * i;
+        if (c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sum2 += v[i][e];
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) sum2 += __shfl_xor(sum2, o);
+    const float mean2 = sum2 / (float)C;
+    float var2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane16 + 16 * i;
+        if (c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float dlt = v[i][e] - mean2; var2 += dlt * dlt; }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) var2 += __shfl_xor(var2, o);
+    const float rstd2 = 1.f / sqrtf(var2 / (float)C + eps2);
+    T* outr2 = out2 + row * ldo2;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane16 + 16 * i;
+        if (c < nchunks) {
+            VC t;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                t[e] = from_f32<T>((v[i][e] - mean2) * rstd2 * gamma2[c * EPC + e] + beta2[c * EPC + e]);
+            *(VC*)(outr2 + c * EPC) = t;
         }
     }
 }
 
 template <typename T>
 int launch_ln(const void* x, long ldx, const float* gamma, const float* beta, void* out, long ldo, long M, int C,
-              float eps, long rpb, long obr, long oro, hipStream_t st) {
+              float eps, long rpb, long obr, long oro, hipStream_t st, const float* gamma2 = nullptr,
+              const float* beta2 = nullptr, void* out2 = nullptr, long ldo2 = 0, float eps2 = 0.f) {
     constexpr int EPC = 16 / (int)sizeof(T);
-    if (C % EPC != 0 || C / EPC > 16 * LN_MAX_CHUNKS || ldx % EPC != 0 || ldo % EPC != 0) return LWDETR_ERR_UNSUPPORTED;
+    if (C % EPC != 0 || C / EPC > 16 * LN_MAX_CHUNKS || ldx % EPC != 0 || ldo % EPC != 0 || ldo2 % EPC != 0) return LWDETR_ERR_UNSUPPORTED;
     const long blocks = (M + 15) / 16;
-    ProfScope ps(KID_LAYERNORM, 0.0, 2.0 * M * C * sizeof(T), st);
+    ProfScope ps(KID_LAYERNORM, 0.0, (gamma2 ? 3.0 : 2.0) * M * C * sizeof(T), st);
     const int nch = (C / EPC + 15) / 16;
 #define LN_LAUNCH(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, \
-                                        ldx, gamma, beta, (T*)out, ldo, M, C, eps, rpb, obr, oro)
+                                        ldx, gamma, beta, (T*)out, ldo, M, C, eps, rpb, obr, oro, gamma2, beta2, (T*)out2, ldo2, eps2)
     if (nch <= 2) LN_LAUNCH(2);
     else if (nch <= 3) LN_LAUNCH(3);
     else if (nch <= 4) LN_LAUNCH(4);
@@ -97,6 +142,20 @@ extern "C" int lwdetr_layernorm(const void* x, long ldx, const float* gamma, con
         case DT_F32: return launch_ln<float>(x, ldx, gamma, beta, out, ldo, M, C, eps, rows_per_batch, out_batch_rows, out_row_offset, st);
         case DT_F16: return launch_ln<f16>(x, ldx, gamma, beta, out, ldo, M, C, eps, rows_per_batch, out_batch_rows, out_row_offset, st);
         case DT_BF16: return launch_ln<bf16>(x, ldx, gamma, beta, out, ldo, M, C, eps, rows_per_batch, out_batch_rows, out_row_offset, st);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int lwdetr_layernorm_chain(const void* x, long ldx, const float* gamma1, const float* beta1, float eps1, void* out1,
+                                      long ldo1, const float* gamma2, const float* beta2, float eps2, void* out2, long ldo2,
+                                      long M, int C, int dtype, void* hip_stream) {
+    if (!x || !gamma1 || !beta1 || !out1 || !gamma2 || !beta2 || !out2 || M < 0 || C <= 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (dtype) {
+        case DT_F32: return launch_ln<float>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2);
+        case DT_F16: return launch_ln<f16>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2);
+        case DT_BF16: return launch_ln<bf16>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
 }

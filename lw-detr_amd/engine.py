@@ -407,9 +407,10 @@ class ForwardPlan:
                 seg(ffn, 0, cfg.dim_feedforward, ldo=cfg.dim_feedforward, bias=pw.f(lay + ".linear1.bias"), act=ACT_RELU)]))
             ops.append(GemmOp(ffn, pw.w(lay + ".linear2.weight"), rq, d, cfg.dim_feedforward, [
                 seg(y, 0, d, ldo=d, bias=pw.f(lay + ".linear2.bias"), res=self.xdec, ldres=d)]))
-            ops.append(LayerNormOp(y, pw.f(lay + ".norm3.weight"), pw.f(lay + ".norm3.bias"), self.xdec, rq, d, 1e-5))
-            ops.append(LayerNormOp(self.xdec, pw.f(f"{t}.decoder.norm.weight"), pw.f(f"{t}.decoder.norm.bias"),
-                                   self.hs[li], rq, d, 1e-5))
+            # norm3, then the shared decoder.norm on its (rounded) output -> hs[li]: one launch
+            ops.append(K.LayerNormChainOp(y, pw.f(lay + ".norm3.weight"), pw.f(lay + ".norm3.bias"), 1e-5, self.xdec,
+                                          pw.f(f"{t}.decoder.norm.weight"), pw.f(f"{t}.decoder.norm.bias"), 1e-5,
+                                          self.hs[li], rq, d))
         # ---- heads on all decoder layers at once
         rh = nl * rq
         hs2 = self.hs.view(rh, d)

@@ -121,6 +121,22 @@ class LayerNormOp:
             _nat.check(rc, "layernorm")
 
 
+class LayerNormChainOp:
+    """out1 = LN1(x); out2 = LN2(out1): one launch (lwdetr_layernorm_chain)."""
+
+    def __init__(self, x, g1, b1, eps1, out1, g2, b2, eps2, out2, M, C_):
+        assert all(t.dtype == torch.float32 for t in (g1, b1, g2, b2))
+        self.args = (_ptr(x), C_, _ptr(g1), _ptr(b1), float(eps1), _ptr(out1), C_, _ptr(g2), _ptr(b2), float(eps2),
+                     _ptr(out2), C_, M, C_, _nat.dtype_code(x.dtype))
+        self._keep = (x, g1, b1, out1, g2, b2, out2)
+        self._fn = _nat.lib().lwdetr_layernorm_chain
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "layernorm_chain")
+
+
 MLP_FUSED_MIN_ROWS = 12800      # below ~8 images of 640x640 the per-tile latency of the fused kernel loses to small GEMMs
 
 

@@ -130,6 +130,29 @@ def test_gemm_conv3x3(dtype, stride, winmajor):
     assert _relerr(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("stride,winmajor,cout", [(1, False, 192), (2, True, 384), (1, True, 128), (2, False, 256)])
+def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, big_gemm):
+    """The implicit-GEMM 3x3 view on the 256-row large-tile kernel (column tiles 192 / 128 / 256), zero padding at the image
+    border, stride 1 | 2, raster and window-major inputs, a channel window inside wider rows - vs F.conv2d."""
+    from lwdetr_amd import kernels as K
+    b, hp, wp, cin, ctot, col0 = 3, 24, 32, 128, 320, 64
+    x = _rand(b, hp, wp, ctot, dtype=dtype, seed=1)
+    w = _rand(cout, cin, 3, 3, dtype=dtype, scale=(9 * cin) ** -0.5, seed=2)
+    bias = _rand(cout, seed=3)
+    twp = (hp // 4) * (wp // 4)
+    a = _to_winmajor(x, twp) if winmajor else x.reshape(-1, ctot)
+    ho, wo = (hp - 1) // stride + 1, (wp - 1) // stride + 1
+    out = torch.zeros(b * ho * wo, cout, dtype=dtype, device=_dev())
+    K.GemmOp(a.contiguous(), w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous(), b * ho * wo, cout, 9 * cin,
+             [K.seg(out, 0, cout, ldo=cout, bias=bias, act=K.ACT_SILU)], lda=ctot, a_mode=K.A_CONV3x3,
+             a_tok=K.tok_layout(winmajor, hp, wp, twp), conv_cin=cin, conv_stride=stride, a_col0=col0, conv_hout=ho,
+             conv_wout=wo)()
+    xin = x[..., col0:col0 + cin].float().permute(0, 3, 1, 2)
+    ref = F.silu(F.conv2d(xin, w.float(), bias, stride=stride, padding=1)).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert _relerr(out, ref) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_deconv2x2_and_tokmap(dtype):
     from lwdetr_amd import kernels as K
@@ -235,7 +258,8 @@ def big_gemm():
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("mnk,depth", [((1000, 768, 768), 2), ((4099, 256, 3072), 2), ((2048, 3072, 768), 64), ((777, 384, 384), 32),
-                                       ((513, 128, 1536), 2), ((300, 640, 1024), 32)])
+                                       ((513, 128, 1536), 2), ((300, 640, 1024), 32), ((700, 576, 512), 2), ((1000, 192, 448), 2),
+                                       ((900, 1152, 384), 2)])
 def test_gemm_large_tile_kernel(dtype, mnk, depth):
     """gemm_big_kernel (256 x 256 / 256 x 128 tiles, 32x32x16 MFMA, DMA ring of 32- and 64-deep stages) vs torch: bias,
     GELU, LayerScale + residual epilogue; ragged M and N tails."""
@@ -261,9 +285,11 @@ def test_gemm_large_tile_kernel(dtype, mnk, depth):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_gemm_large_tile_kernel_head_layouts(dtype, big_gemm):
-    """QKV of the C = 768 model through the large-tile kernel: HEADS (q, k) and HEADS_T (V^T, swapped MFMA operands)."""
-    _check_qkv_layouts(dtype, 64, 4, 1600)
+@pytest.mark.parametrize("hd", [64, 32, 16])
+def test_gemm_large_tile_kernel_head_layouts(dtype, hd, big_gemm):
+    """QKV of the C = 768 / 384 / 192 models through the large-tile kernel (column tiles 256 / 192 / 192): HEADS (q, k) and
+    HEADS_T (V^T, swapped MFMA operands)."""
+    _check_qkv_layouts(dtype, hd, 4, 1600)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -283,6 +309,21 @@ def test_layernorm(dtype, c):
     K.LayerNormOp(xb, g, b, ob, 2 * rows, c, 1e-6, rows_per_batch=rows, out_batch_rows=s_total, out_row_offset=off)()
     refb = F.layer_norm(xb.float(), (c,), g, b, 1e-6).reshape(2, rows, c)
     assert (ob.reshape(2, s_total, c)[:, off:off + rows].float() - refb).abs().max().item() < 6e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [256, 384])
+def test_layernorm_chain_is_bit_identical_to_two_launches(dtype, c):
+    """norm3 + decoder.norm in one launch (lwdetr_layernorm_chain) == two lwdetr_layernorm launches, bit for bit."""
+    from lwdetr_amd import kernels as K
+    m = 9600
+    x = _rand(m, c, dtype=dtype, seed=1) * 3
+    g1, b1, g2, b2 = (_rand(c, seed=s_) for s_ in (2, 3, 4, 5))
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    K.LayerNormChainOp(x, g1, b1, 1e-5, o1, g2, b2, 1e-6, o2, m, c)()
+    r1 = K.layernorm(x, g1, b1, 1e-5)
+    r2 = K.layernorm(r1, g2, b2, 1e-6)
+    assert torch.equal(o1, r1) and torch.equal(o2, r2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

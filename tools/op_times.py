@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--res", type=int, default=640)
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--gemm-big", type=int, default=-1, help="lwdetr_gemm_tuning mode: compare every GEMM with mode 0 / this mode")
     a = ap.parse_args()
     import torch
     import lwdetr_amd
@@ -58,7 +59,21 @@ def main():
             ts.sort()
             med = ts[len(ts) // 2]
             total += med
-            print(f"{gname:8s} {i:3d} {med:8.1f} us  {describe(op, K)}")
+            extra = ""
+            if a.gemm_big >= 0 and isinstance(op, K.GemmOp):
+                _native.lib().lwdetr_gemm_tuning(a.gemm_big)
+                t2 = []
+                for _ in range(20):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    op(stream)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t2.append(e0.elapsed_time(e1) * 1e3)
+                _native.lib().lwdetr_gemm_tuning(-1)
+                t2.sort()
+                extra = f"   [gemm_tuning({a.gemm_big}): {t2[len(t2) // 2]:8.1f} us]"
+            print(f"{gname:8s} {i:3d} {med:8.1f} us  {describe(op, K)}{extra}")
     print(f"sum of medians: {total:.1f} us")
 
 
