@@ -41,7 +41,13 @@ extern "C" int lwdetr_debug_mlp_timing(unsigned long long* out) {
 
 namespace {
 
-constexpr int NW = 8, NTHR = NW * 64;      // waves / threads per workgroup
+#ifndef MLP_NW
+#define MLP_NW 8
+#endif
+#ifndef MLP_TT384
+#define MLP_TT384 1
+#endif
+constexpr int NW = MLP_NW, NTHR = NW * 64;      // waves / threads per workgroup (tuning builds: -DMLP_NW=4 -DMLP_WAVES_PER_SIMD=1)
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 bytes, lane l lands at lds_wave_base + 16 l; source = sbase + voff (bytes).
 // Issued through inline assembly on purpose: hipcc treats the builtin form as a FLAT access that may touch LDS, and while
@@ -826,8 +832,8 @@ extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const 
     p.out2 = out2; p.ld2 = ld2; p.stats_out = stats_out; p.M = M; p.eps = eps; p.eps_next = eps_next;
     hipStream_t st = (hipStream_t)hip_stream;
     switch (dtype) {
-        case DT_F16: return dispatch_c<f16, 2, 1>(p, C, st);
-        case DT_BF16: return dispatch_c<bf16, 2, 1>(p, C, st);
+        case DT_F16: return dispatch_c<f16, 2, MLP_TT384>(p, C, st);
+        case DT_BF16: return dispatch_c<bf16, 2, MLP_TT384>(p, C, st);
         case DT_F32: return dispatch_c<float, 1, 1>(p, C, st);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
