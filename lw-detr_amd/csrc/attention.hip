@@ -664,6 +664,9 @@ static bool lds_path_applies(const lwdetr_attn_desc& p) {
     // hd16 B32: 36 | 54, hd32 B64: 113 | 124 - a 100-key sequence is over after two stages, the ring never pays for its start-up
     if (p.keys_per_seq < (mode == 1 ? 512 : (mode == 3 ? 64 : 192))) return false;
     if (p.keys_per_seq % 8 != 0 && !p.vt_slack) return false;
+    // a grid that cannot fill the chip (single image: 7 x 12 workgroups of 256 queries) is faster on attn_kernel's 128-query
+    // workgroups: 21.7 vs 27.0 us at B = 1, hd 16, 1600 keys (tools/attn_bench.py small_b1_f16)
+    if (mode != 3 && (long)((p.keys_per_seq + 255) / 256) * p.heads * p.B * p.seqs_per_img < 256) return false;
     return p.keys_per_seq % 4 == 0 && p.seq_tok_stride % 4 == 0 && p.Tp % 4 == 0 && p.ldo % 8 == 0 &&
            (p.sub_len == p.sub_stride || p.sub_stride >= 64);
 }

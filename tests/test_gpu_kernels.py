@@ -225,7 +225,10 @@ def test_attention(dtype, hd, geom):
     vt = vt_store[:v.numel()].view(b, heads, hd, tp)
     vt.copy_(v.transpose(2, 3))
     from lwdetr_amd import _native
-    _native.lib().lwdetr_attention_tuning(3 if slack else -1)        # _slack cases: LDS-ring kernel for every length >= 64
+    # LDS-ring kernel for every 16-bit case it can serve (by default it only takes grids that fill the chip and >= 192 keys;
+    # these test batches are small); the other geometries / f32 exercise attn_kernel
+    use_lds = slack or geom in ("global1600", "holes3648", "global704")
+    _native.lib().lwdetr_attention_tuning(3 if use_lds else -1)
     try:
         K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd,
                  seqs_per_img=spi, seq_tok_stride=twp if spi == 16 else tp, keys_per_seq=keys, sub_stride=twp,
