@@ -24,6 +24,7 @@
  *   lwdetr_attention           models/backbone/vit.py:130-137 (window and global softmax(QK^T)V) and
  *                              models/attention.py:563-606 (decoder self-attention)
  *   lwdetr_mlp_fused           models/backbone/vit.py:217-218 (+ timm.models.layers.Mlp: fc1 -> GELU -> fc2)
+ *   lwdetr_ffn_partial/_finish models/transformer.py:507-512, :397-400 (decoder FFN + norm3 + decoder.norm)
  *   lwdetr_layernorm           nn.LayerNorm call sites (vit.py:199,:217; transformer.py:231,:499,:511,:516,:398) and
  *                              the channel LayerNorm of models/backbone/projector.py:21-47
  */
@@ -146,6 +147,22 @@ int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* b
 int lwdetr_layernorm_chain(const void* x, long ldx, const float* gamma1, const float* beta1, float eps1, void* out1, long ldo1,
                            const float* gamma2, const float* beta2, float eps2, void* out2, long ldo2, long M, int C,
                            int dtype, void* hip_stream);
+
+/* ---- decoder FFN in two launches, hidden activation on chip --------------------------------------------------------
+ * Replaces models/transformer.py:507-512 (linear2(dropout(relu(linear1(tgt)))) + residual + norm3) and the shared
+ * decoder.norm that follows (:397-400). lwdetr_ffn_partial: the grid is (token tiles) x (splits of the hidden dimension);
+ * every workgroup keeps ReLU(x W1^T + b1) of its hidden slice in registers and writes the f32 partial product with W2 to
+ * partial[split] (M, C) - the 300-queries-per-image row count alone cannot fill 256 CUs, the hidden split can.
+ * lwdetr_ffn_finish: x + b2 + sum of the partial slabs (rounded to the 16-bit dtype, as the unfused GEMM epilogue rounds),
+ * out1 = LN1(.), optionally out2 = LN2(out1). w1 (hid, C) plain row-major; w2_chunked (hid/32, C, 32) as for
+ * lwdetr_mlp_fused. C in {256, 384}, hid % 64 == 0, 16-bit dtypes. lwdetr_ffn_splits returns the number of slabs the
+ * launch for (M, C, hid) writes (> 0), or -error. */
+int lwdetr_ffn_splits(long M, int C, int hid, int dtype);
+int lwdetr_ffn_partial(const void* x, long ldx, const void* w1, const float* b1, const void* w2_chunked, float* partial, long M,
+                       int C, int hid, int dtype, void* hip_stream);
+int lwdetr_ffn_finish(const void* x, long ldx, const float* partial, int splits, const float* b2, const float* gamma1,
+                      const float* beta1, float eps1, void* out1, long ldo1, const float* gamma2, const float* beta2, float eps2,
+                      void* out2, long ldo2, long M, int C, int dtype, void* hip_stream);
 
 /* ---- fused ViT MLP: x <- x + gamma2 * fc2(GELU(fc1(LN(x)))), one launch, hidden activation stays on chip ---------
  * Replaces models/backbone/vit.py:217-218 (norm2 -> timm Mlp -> gamma_2 -> residual). Weight packing (host, once):

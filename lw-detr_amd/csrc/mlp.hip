@@ -83,10 +83,15 @@ struct MlpParams {
     const void* att; long ldatt; const void* wp; const float* bp; const float* gamma1;
     // optional chained LayerNorm + QKV projection of the NEXT block on the updated rows (vit.py:199, :123-130)
     const void* wqkv; const float* bqkv; void* q; void* k; void* vt; float qscale; int heads, hd, Tp;
+    // FFN mode (decoder: linear1 -> ReLU -> linear2, models/transformer.py:507-512): workgroup (x, y) walks hidden chunks
+    // [y * chunks_per_split, (y + 1) * chunks_per_split) of its tiles and writes the f32 partial products of linear2 to
+    // partial[y][m][C]; no LayerNorm, no residual (lwdetr_ffn_finish sums the slabs)
+    float* partial; int chunks_per_split;
 };
 
-template <typename T, int C, int TT, bool PROJ, bool QKV>
+template <typename T, int C, int TT, bool PROJ, bool QKV, bool FFN = false>
 __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const MlpParams p) {
+    static_assert(!FFN || (!PROJ && !QKV), "FFN mode has no projection / chained QKV");
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     constexpr int KC = C / 32;                 // k-chunks of step 1
@@ -176,7 +181,11 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     constexpr int XCHG = QKV ? NW * 16 * TT * (C + 2 * EPC) : 0;
     T* x1s = smem + 2 * TILE_STRIDE + (wave < X1_TILES ? wave : 0) * 16 * TT * X1_LD;      // this wave's x1 rows (X1LDS)
     float* b1s = (float*)(smem + (2 * TILE_STRIDE + X1_ELEMS > XCHG ? 2 * TILE_STRIDE + X1_ELEMS : XCHG));
-    for (int i = tid; i < HID; i += NTHR) b1s[i] = p.b1[i];
+    // hidden chunks of this workgroup: all of them (ViT block) or the slice of its split (FFN mode; HID floats of LDS hold it)
+    const int hc0 = FFN ? (int)blockIdx.y * p.chunks_per_split : 0;
+    const int hc1 = FFN ? hc0 + p.chunks_per_split : NCH;
+    if (FFN) { for (int i = tid; i < (hc1 - hc0) * 32; i += NTHR) b1s[i] = p.b1[hc0 * 32 + i]; }
+    else { for (int i = tid; i < HID; i += NTHR) b1s[i] = p.b1[i]; }
     float* bps = b1s + HID;
     if (PROJ) for (int i = tid; i < C; i += NTHR) { bps[i] = p.bp[i]; bps[C + i] = p.gamma1[i]; }
     float* bqs = bps + 2 * C;
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     // ---- prologue: token rows -> B-operand fragments xf (lane: token l15, 8 channels per k-chunk)
     V8 xf[TT][KC];
     if (!PROJ) {
-        stage_w(0, 0);
+        stage_w(hc0, 0);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             long m = m_wave + t * 16 + l15; m = m < p.M ? m : p.M - 1;
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     TSTAMP(1);
     // ---- LayerNorm in registers (two-pass f32 statistics; the affine part is folded into W1 / b1 on the host)
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < (FFN ? 0 : TT); ++t) {
         float s = 0.f;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
@@ -300,13 +309,13 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
 
     if (!PROJ) dma_sync();
     TSTAMP(2);
-    for (int hc = 0; hc < NCH; ++hc) {
-        const int buf = hc & 1;
-        if (hc + 1 < NCH) stage_w(hc + 1, buf ^ 1);
+    for (int hc = hc0; hc < hc1; ++hc) {
+        const int buf = (hc - hc0) & 1;
+        if (hc + 1 < hc1) stage_w(hc + 1, buf ^ 1);
         const T* w1s = smem + buf * TILE_STRIDE;
         const T* w2s = w1s + W1_TILE_PAD;
         // bias of this lane's 8 hidden units (rows 4g..4g+3 of the two 16-row tiles): the accumulators start from it
-        const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
+        const f32x4 bia0 = *(const f32x4*)(b1s + (hc - hc0) * 32 + g * 4), bia1 = *(const f32x4*)(b1s + (hc - hc0) * 32 + 16 + g * 4);
         // The 2*KC + NT weight fragments of the chunk are read through a ring RD deep: the read of fragment i + RD is
         // issued before the MFMAs of fragment i, so an LDS round trip is never exposed (left alone, hipcc issues every
         // ds_read right in front of its MFMAs and waits for it: ~100 exposed cycles per 34 cycles of MFMA).
@@ -341,8 +350,8 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
         for (int t = 0; t < TT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hf[t][e] = from_f32<T>(gelu_for<T>(acc1[0][t][e]));
-                hf[t][4 + e] = from_f32<T>(gelu_for<T>(acc1[1][t][e]));
+                hf[t][e] = from_f32<T>(FFN ? fmaxf(acc1[0][t][e], 0.f) : gelu_for<T>(acc1[0][t][e]));
+                hf[t][4 + e] = from_f32<T>(FFN ? fmaxf(acc1[1][t][e], 0.f) : gelu_for<T>(acc1[1][t][e]));
             }
         __builtin_amdgcn_sched_barrier(0);
         // ---- step 2
@@ -359,6 +368,18 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
     }
 
     TSTAMP(3);
+    if (FFN) {      // partial linear2 products of this hidden slice: f32, lane holds channels n*16 + 4g .. +3 of token l15
+        float* __restrict__ part = p.partial + (long)blockIdx.y * p.M * C;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const long m = m_wave + t * 16 + l15;
+            if (m < p.M) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) *(f32x4*)(part + m * C + n * 16 + g * 4) = acc2[n][t];
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds channels n*16 + 4g .. +3 of token l15
     T* __restrict__ O2 = (T*)p.out2;
     V8 xq[QKV ? TT : 1][QKV ? KC : 1];
@@ -785,6 +806,44 @@ int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     return lwdetr_check_launch();
 }
 
+// FFN mode launch: full workgroups (8 tiles each) x S hidden splits, S = the largest power of two that keeps the grid within
+// one workgroup per CU (the weight tiles take the LDS of a CU) and leaves every split at least two chunks (double buffer).
+constexpr int FFN_MAX_SPLITS = 16;   // measured (tools/ffn_bench.py, M = 300): 32 -> 22.3 us, 16 -> 20.0, 8 -> 22.1, 4 -> 30.4
+template <typename T, int C, int TT>
+int launch_ffn(const MlpParams& p0, int hid, hipStream_t st, int* splits_out) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int PIECE = 64 * EPC;
+    constexpr int W1P = (32 * (C + 2 * EPC) + PIECE - 1) / PIECE * PIECE, W2P = (C * (32 + 2 * EPC) + PIECE - 1) / PIECE * PIECE;
+    constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 9 * C * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done = true;
+    }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LWDETR_ERR_LAUNCH;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    MlpParams q = p0;
+    q.ntiles = (int)((p0.M + 16 * TT - 1) / (16 * TT));
+    int blocks = (q.ntiles + NW - 1) / NW;
+    const int nch = hid / 32;
+    int S = 1;
+    while ((long)(nch / S) * 32 > 4 * C && nch % (S * 2) == 0) S *= 2;       // the bias slice lives in the 4C floats of LDS
+    if ((long)(nch / S) * 32 > 4 * C) return LWDETR_ERR_UNSUPPORTED;
+    static const int s_max = getenv("LWDETR_FFN_SPLITS") ? atoi(getenv("LWDETR_FFN_SPLITS")) : FFN_MAX_SPLITS;   // tuning
+    while (S * 2 * blocks <= ncu && nch % (S * 2) == 0 && nch / (S * 2) >= 2 && S * 2 <= s_max) S *= 2;
+    if (ncu / S > blocks) blocks = ncu / S < q.ntiles ? ncu / S : q.ntiles;   // spare CUs: fewer tiles per workgroup
+    q.chunks_per_split = nch / S;
+    if (splits_out) { *splits_out = S; return LWDETR_OK; }
+    ProfScope ps(KID_MLP, 4.0 * p0.M * C * hid, (double)p0.M * C * (sizeof(T) + 4.0 * S) + 2.0 * C * hid * sizeof(T), st);
+    hipLaunchKernelGGL((mlp_kernel<T, C, TT, false, false, true>), dim3((unsigned)blocks, (unsigned)S), dim3(NTHR), lds, st, q);
+    return lwdetr_check_launch();
+}
+
 constexpr long MLP_SMALL_MAX_ROWS = 12800;       // below ~8 images the tile-per-workgroup kernel wins (see mlp_small_kernel)
 
 template <typename T, int C, int TT>
@@ -837,4 +896,39 @@ extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const 
         case DT_F32: return dispatch_c<float, 1, 1>(p, C, st);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
+}
+
+// ---- decoder FFN, first half: partial[s] (M, C) f32 = ReLU(x W1[hs]^T + b1[hs]) W2[:, hs]^T over the hidden slice hs of split s.
+// w2_chunked as for lwdetr_mlp_fused (hidden x C chunk-major with the k-slot permutation), w1 (hid, C) plain. C in {256, 384}.
+// splits: the number of slabs the kernel writes (query it with lwdetr_ffn_splits, size `partial` as splits * M * C floats).
+template <typename T>
+static int ffn_dispatch(const MlpParams& p, int C, int hid, hipStream_t st, int* splits_out) {
+    switch (C) {
+        case 256: return launch_ffn<T, 256, 2>(p, hid, st, splits_out);
+        case 384: return launch_ffn<T, 384, 1>(p, hid, st, splits_out);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}
+static int ffn_entry(const void* x, long ldx, const void* w1, const float* b1, const void* w2_chunked, float* partial, long M,
+                     int C, int hid, int dtype, void* hip_stream, int* splits_out) {
+    if (M < 0 || hid <= 0 || hid % 64 != 0 || ldx % 8 != 0) return LWDETR_ERR_BAD_ARG;
+    MlpParams p = {};
+    p.x = (void*)x; p.ldx = ldx; p.w1 = w1; p.b1 = b1; p.w2p = w2_chunked; p.M = M; p.partial = partial;
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (dtype) {
+        case DT_F16: return ffn_dispatch<f16>(p, C, hid, st, splits_out);
+        case DT_BF16: return ffn_dispatch<bf16>(p, C, hid, st, splits_out);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}
+extern "C" int lwdetr_ffn_splits(long M, int C, int hid, int dtype) {
+    int s = 0;
+    const int rc = ffn_entry(nullptr, 0, nullptr, nullptr, nullptr, nullptr, M, C, hid, dtype, nullptr, &s);
+    return rc == LWDETR_OK ? s : -rc;
+}
+extern "C" int lwdetr_ffn_partial(const void* x, long ldx, const void* w1, const float* b1, const void* w2_chunked, float* partial,
+                                  long M, int C, int hid, int dtype, void* hip_stream) {
+    if (!x || !w1 || !b1 || !w2_chunked || !partial) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    return ffn_entry(x, ldx, w1, b1, w2_chunked, partial, M, C, hid, dtype, hip_stream, nullptr);
 }

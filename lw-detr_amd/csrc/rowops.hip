@@ -16,7 +16,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                                                         long M, int C, float eps, long rows_per_batch,
                                                         long out_batch_rows, long out_row_offset,
                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2,
-                                                        T* __restrict__ out2, long ldo2, float eps2) {
+                                                        T* __restrict__ out2, long ldo2, float eps2,
+                                                        const float* __restrict__ part, int nsplit,
+                                                        const float* __restrict__ pbias) {
     constexpr int EPC = 16 / (int)sizeof(T);
     typedef T VC __attribute__((ext_vector_type(EPC)));
     const int lane16 = threadIdx.x & 15;
@@ -32,7 +34,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
         if (c < nchunks) {
             const VC t = *(const VC*)(xr + c * EPC);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { v[i][e] = to_f32<T>(t[e]); sum += v[i][e]; }
+            for (int e = 0; e < EPC; ++e) v[i][e] = to_f32<T>(t[e]);
+            if (part) {     // FFN finish: row = T(x + bias + sum of the f32 split-hidden partial products), then the LayerNorms
+                float a[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) a[e] = pbias[c * EPC + e];
+#pragma unroll 4
+                for (int sidx = 0; sidx < nsplit; ++sidx) {
+                    const float* pr = part + ((long)sidx * M + row) * C + c * EPC;
+#pragma unroll
+                    for (int e4 = 0; e4 < EPC; e4 += 4) {
+                        const f32x4 q = *(const f32x4*)(pr + e4);
+                        a[e4] += q[0]; a[e4 + 1] += q[1]; a[e4 + 2] += q[2]; a[e4 + 3] += q[3];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[i][e] = to_f32<T>(from_f32<T>(v[i][e] + a[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sum += v[i][e];
         }
     }
 #pragma unroll
@@ -111,14 +131,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 template <typename T>
 int launch_ln(const void* x, long ldx, const float* gamma, const float* beta, void* out, long ldo, long M, int C,
               float eps, long rpb, long obr, long oro, hipStream_t st, const float* gamma2 = nullptr,
-              const float* beta2 = nullptr, void* out2 = nullptr, long ldo2 = 0, float eps2 = 0.f) {
+              const float* beta2 = nullptr, void* out2 = nullptr, long ldo2 = 0, float eps2 = 0.f,
+              const float* part = nullptr, int nsplit = 0, const float* pbias = nullptr) {
     constexpr int EPC = 16 / (int)sizeof(T);
     if (C % EPC != 0 || C / EPC > 16 * LN_MAX_CHUNKS || ldx % EPC != 0 || ldo % EPC != 0 || ldo2 % EPC != 0) return LWDETR_ERR_UNSUPPORTED;
     const long blocks = (M + 15) / 16;
-    ProfScope ps(KID_LAYERNORM, 0.0, (gamma2 ? 3.0 : 2.0) * M * C * sizeof(T), st);
+    ProfScope ps(KID_LAYERNORM, 0.0, (gamma2 ? 3.0 : 2.0) * M * C * sizeof(T) + 4.0 * nsplit * M * C, st);
     const int nch = (C / EPC + 15) / 16;
 #define LN_LAUNCH(N) hipLaunchKernelGGL((layernorm_kernel<T, N>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, \
-                                        ldx, gamma, beta, (T*)out, ldo, M, C, eps, rpb, obr, oro, gamma2, beta2, (T*)out2, ldo2, eps2)
+                                        ldx, gamma, beta, (T*)out, ldo, M, C, eps, rpb, obr, oro, gamma2, beta2, (T*)out2, ldo2, eps2, \
+                                        part, nsplit, pbias)
     if (nch <= 2) LN_LAUNCH(2);
     else if (nch <= 3) LN_LAUNCH(3);
     else if (nch <= 4) LN_LAUNCH(4);
@@ -156,6 +178,22 @@ extern "C" int lwdetr_layernorm_chain(const void* x, long ldx, const float* gamm
         case DT_F32: return launch_ln<float>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2);
         case DT_F16: return launch_ln<f16>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2);
         case DT_BF16: return launch_ln<bf16>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}
+
+// decoder FFN, second half: x <- T(x + b2 + sum_s partial[s]); out1 = norm3(x); out2 = decoder.norm(out1) (16-bit only:
+// the producer, lwdetr_ffn_partial, runs on the 16-bit MFMA block kernel)
+extern "C" int lwdetr_ffn_finish(const void* x, long ldx, const float* partial, int splits, const float* b2, const float* gamma1,
+                                 const float* beta1, float eps1, void* out1, long ldo1, const float* gamma2, const float* beta2,
+                                 float eps2, void* out2, long ldo2, long M, int C, int dtype, void* hip_stream) {
+    if (!x || !partial || splits <= 0 || !b2 || !gamma1 || !beta1 || !out1 || M < 0 || C <= 0 || C % 8 != 0) return LWDETR_ERR_BAD_ARG;
+    if (gamma2 && (!beta2 || !out2)) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (dtype) {
+        case DT_F16: return launch_ln<f16>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2, partial, splits, b2);
+        case DT_BF16: return launch_ln<bf16>(x, ldx, gamma1, beta1, out1, ldo1, M, C, eps1, 0, 0, 0, st, gamma2, beta2, out2, ldo2, eps2, partial, splits, b2);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
 }

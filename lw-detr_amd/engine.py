@@ -12,6 +12,7 @@ Dead compute of the reference that is not executed (results unused, SURVEY.md se
 memory, head-averaged self-attention weights, per-call bicubic pos-embed resize (cached per resolution).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -371,7 +372,11 @@ class ForwardPlan:
         ops.append(GemmOp(self.sine, pw.w(rp + ".0.weight"), rq, d, 2 * d, [seg(r1, 0, d, ldo=d, bias=pw.f(rp + ".0.bias"), act=ACT_RELU)]))
         ops.append(GemmOp(r1, pw.w(rp + ".1.weight"), rq, d, d, [seg(self.qpos, 0, d, ldo=d, bias=pw.f(rp + ".1.bias"))]))
         qd, kd, vtd = z(B, sa_h, nq, sa_hd), z(B, sa_h, nq, sa_hd), z(B, sa_h, sa_hd, nq)
-        attd, y, ca, ffn = z(rq, d), z(rq, d), z(rq, d), z(rq, cfg.dim_feedforward)
+        attd, y, ca = z(rq, d), z(rq, d), z(rq, d)
+        # decoder FFN: two launches with the hidden activation on chip (lwdetr_ffn_partial / _finish) unless
+        # LWDETR_FFN_FUSED=0 (three launches: linear1 + ReLU, linear2 + residual, LayerNorm chain)
+        ffn_fused = K.ffn_fused_supported(d, cfg.dim_feedforward, self.T) and os.environ.get("LWDETR_FFN_FUSED", "1") != "0"
+        ffn = None if ffn_fused else z(rq, cfg.dim_feedforward)
         lp3 = M * L * P * 3
         ld_oa = _ceil4(lp3)
         oa = z(rq, ld_oa)
@@ -403,14 +408,20 @@ class ForwardPlan:
             ops.append(GemmOp(ca, pw.w(ca_p + ".output_proj.weight"), rq, d, d, [
                 seg(y, 0, d, ldo=d, bias=pw.f(ca_p + ".output_proj.bias"), res=self.xdec, ldres=d)]))
             ops.append(LayerNormOp(y, pw.f(lay + ".norm2.weight"), pw.f(lay + ".norm2.bias"), self.xdec, rq, d, 1e-5))
+            n3 = (pw.f(lay + ".norm3.weight"), pw.f(lay + ".norm3.bias"), 1e-5, self.xdec,
+                  pw.f(f"{t}.decoder.norm.weight"), pw.f(f"{t}.decoder.norm.bias"), 1e-5, self.hs[li], rq, d)
+            if ffn_fused:
+                w1, b1, w2c = pw.custom_multi(lay + ".ffn.packed", lambda lay=lay: K.pack_mlp_weights(
+                    pw.sd[lay + ".linear1.weight"], pw.sd[lay + ".linear1.bias"], pw.sd[lay + ".linear2.weight"], None, None,
+                    self.T))
+                ops.append(K.FfnOp(self.xdec, w1, b1, w2c, pw.f(lay + ".linear2.bias"), *n3))
+                continue
             ops.append(GemmOp(self.xdec, pw.w(lay + ".linear1.weight"), rq, cfg.dim_feedforward, d, [
                 seg(ffn, 0, cfg.dim_feedforward, ldo=cfg.dim_feedforward, bias=pw.f(lay + ".linear1.bias"), act=ACT_RELU)]))
             ops.append(GemmOp(ffn, pw.w(lay + ".linear2.weight"), rq, d, cfg.dim_feedforward, [
                 seg(y, 0, d, ldo=d, bias=pw.f(lay + ".linear2.bias"), res=self.xdec, ldres=d)]))
             # norm3, then the shared decoder.norm on its (rounded) output -> hs[li]: one launch
-            ops.append(K.LayerNormChainOp(y, pw.f(lay + ".norm3.weight"), pw.f(lay + ".norm3.bias"), 1e-5, self.xdec,
-                                          pw.f(f"{t}.decoder.norm.weight"), pw.f(f"{t}.decoder.norm.bias"), 1e-5,
-                                          self.hs[li], rq, d))
+            ops.append(K.LayerNormChainOp(y, *n3))
         # ---- heads on all decoder layers at once
         rh = nl * rq
         hs2 = self.hs.view(rh, d)

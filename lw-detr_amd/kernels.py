@@ -137,6 +137,41 @@ class LayerNormChainOp:
             _nat.check(rc, "layernorm_chain")
 
 
+def ffn_fused_supported(C_, hid, dtype) -> bool:
+    """Shapes lwdetr_ffn_partial is instantiated for (the decoder widths of the shipped configurations)."""
+    return C_ in (256, 384) and hid % 64 == 0 and dtype in (torch.float16, torch.bfloat16)
+
+
+class FfnOp:
+    """Decoder FFN + norm3 (+ decoder.norm): x_out = LN1(x + W2 ReLU(W1 x + b1) + b2), hs = LN2(x_out); two launches
+    (lwdetr_ffn_partial, lwdetr_ffn_finish). ``w1, b1, w2c`` from ``pack_mlp_weights(..., ln_w=None, ln_b=None)``."""
+
+    def __init__(self, x, w1, b1, w2c, b2, g1, be1, eps1, out1, g2, be2, eps2, out2, M, C_):
+        hid = w1.shape[0]
+        assert all(t.dtype == torch.float32 for t in (b1, b2, g1, be1)) and w1.dtype == x.dtype == w2c.dtype
+        code = _nat.dtype_code(x.dtype)
+        splits = _nat.lib().lwdetr_ffn_splits(M, C_, hid, code)
+        if splits <= 0:
+            _nat.check(-splits if splits < 0 else 2, "ffn_splits")
+        self.splits = splits
+        self.partial = torch.empty(splits, M, C_, dtype=torch.float32, device=x.device)
+        self.a_part = (_ptr(x), C_, _ptr(w1), _ptr(b1), _ptr(w2c), _ptr(self.partial), M, C_, hid, code)
+        self.a_fin = (_ptr(x), C_, _ptr(self.partial), splits, _ptr(b2), _ptr(g1), _ptr(be1), float(eps1), _ptr(out1), C_,
+                      _ptr(g2) if g2 is not None else None, _ptr(be2) if g2 is not None else None, float(eps2),
+                      _ptr(out2) if g2 is not None else None, C_, M, C_, code)
+        self._keep = (x, w1, b1, w2c, b2, g1, be1, out1, g2, be2, out2)
+        self._f_part, self._f_fin = _nat.lib().lwdetr_ffn_partial, _nat.lib().lwdetr_ffn_finish
+
+    def __call__(self, stream=None):
+        st = stream if stream is not None else _nat.stream_ptr()
+        rc = self._f_part(*self.a_part, st)
+        if rc:
+            _nat.check(rc, "ffn_partial")
+        rc = self._f_fin(*self.a_fin, st)
+        if rc:
+            _nat.check(rc, "ffn_finish")
+
+
 MLP_FUSED_MIN_ROWS = 12800      # below ~8 images of 640x640 the per-tile latency of the fused kernel loses to small GEMMs
 
 
@@ -165,17 +200,21 @@ _KSLOT_PERM = [4 * g_ + e + 16 * hi for g_ in range(4) for hi in range(2) for e 
 def pack_mlp_weights(w1, b1, w2, ln_w, ln_b, dtype, proj=False):
     """Host-side packing for lwdetr_mlp_fused (f32 master tensors in, device tensors of ``dtype`` / f32 out):
     LayerNorm's affine is folded into fc1, fc2 is re-laid out chunk-major (32 hidden units per contiguous tile)."""
-    w1, b1, w2, ln_w, ln_b = (t.float() for t in (w1, b1, w2, ln_w, ln_b))
-    c = w1.shape[1]
-    b1f = (b1 + w1 @ ln_b).contiguous()
-    w1f = w1 * ln_w[None, :]
+    w1, b1, w2 = (t.float() for t in (w1, b1, w2))
+    hid, c = w1.shape
+    if ln_w is None:            # decoder FFN (lwdetr_ffn_partial): no LayerNorm in front of linear1
+        b1f, w1f = b1.contiguous(), w1
+    else:
+        ln_w, ln_b = ln_w.float(), ln_b.float()
+        b1f = (b1 + w1 @ ln_b).contiguous()
+        w1f = w1 * ln_w[None, :]
     if proj:   # the fused projection hands x over in accumulator order: permute fc1's columns inside every 32-chunk
-        w1f = w1f.view(4 * c, c // 32, 32)[:, :, torch.tensor(_KSLOT_PERM)].reshape(4 * c, c)
+        w1f = w1f.view(hid, c // 32, 32)[:, :, torch.tensor(_KSLOT_PERM)].reshape(hid, c)
     w1f = w1f.to(dtype).contiguous()
     # chunk-major, and inside a chunk the MFMA k-slot order of the fused kernel: lane group g holds hidden
     # (4g..4g+3, 16+4g..16+4g+3) as one contiguous run of 8
     perm = torch.tensor(_KSLOT_PERM)
-    w2c = w2.view(c, (4 * c) // 32, 32)[:, :, perm].permute(1, 0, 2).to(dtype).contiguous()
+    w2c = w2.view(c, hid // 32, 32)[:, :, perm].permute(1, 0, 2).to(dtype).contiguous()
     return w1f, b1f, w2c
 
 

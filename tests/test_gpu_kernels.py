@@ -329,6 +329,44 @@ def test_layernorm_chain_is_bit_identical_to_two_launches(dtype, c):
     assert torch.equal(o1, r1) and torch.equal(o2, r2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("c,hid,m", [(256, 2048, 9600), (256, 2048, 300), (256, 2048, 19200), (384, 2048, 4800), (384, 2048, 301),
+                                     (256, 1024, 77), (256, 2048, 40000), (256, 64, 100)])
+def test_ffn_fused(dtype, c, hid, m):
+    """Decoder FFN (split-hidden partial products + finishing LayerNorm chain, two launches) vs the torch fp32 formulation
+    of transformer.py:507-512 / :397-400 and vs the unfused three-launch plan. 9600 / 19200 = 32 / 64 images x 300 queries
+    (BASELINE configs 2-4), 300 = one image, 40000 = more tiles than one workgroup per CU takes, 64 = a single chunk pair."""
+    from lwdetr_amd import kernels as K
+    assert K.ffn_fused_supported(c, hid, dtype)
+    x = _rand(m, c, dtype=dtype, seed=1)
+    w1, b1 = _rand(hid, c, scale=c ** -0.5, seed=2), _rand(hid, seed=3) * 0.1
+    w2, b2 = _rand(c, hid, scale=hid ** -0.5, seed=4), _rand(c, seed=5) * 0.1
+    g1, be1 = _rand(c, seed=6) * 0.2 + 1, _rand(c, seed=7) * 0.1
+    g2, be2 = _rand(c, seed=8) * 0.2 + 1, _rand(c, seed=9) * 0.1
+    xf = x.float()
+    r1 = F.layer_norm(xf + F.relu(xf @ w1.t() + b1) @ w2.t() + b2, (c,), g1, be1, 1e-5)
+    r2 = F.layer_norm(r1, (c,), g2, be2, 1e-5)
+    w1p, b1p, w2c = K.pack_mlp_weights(w1, b1, w2, None, None, dtype)
+    assert torch.equal(w1p, w1.to(dtype)) and torch.equal(b1p, b1)
+    o1, o2 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    op = K.FfnOp(x, w1p, b1p, w2c, b2, g1, be1, 1e-5, o1, g2, be2, 1e-5, o2, m, c)
+    assert op.splits >= 1 and (hid // 32) % op.splits == 0
+    op()
+    tol = {torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
+    assert _relerr(o1, r1) < tol, _relerr(o1, r1)
+    assert _relerr(o2, r2) < tol, _relerr(o2, r2)
+    # the unfused plan (two GEMM launches + LayerNorm chain) on the same 16-bit weights: same roundings up to f32 summation order
+    h = K.linear(x, w1.to(dtype), b1, act=K.ACT_RELU)
+    y = K.linear(h, w2.to(dtype), b2, res=x)
+    u1 = K.layernorm(y, g1, be1, 1e-5)
+    assert _relerr(o1, u1) < tol / 2, _relerr(o1, u1)
+    # in place (the engine's use: out1 aliases x), and deterministic
+    xx = x.clone()
+    o3 = torch.empty_like(x)
+    K.FfnOp(xx, w1p, b1p, w2c, b2, g1, be1, 1e-5, xx, g2, be2, 1e-5, o3, m, c)()
+    assert torch.equal(xx, o1) and torch.equal(o3, o2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c,m", [(192, 1000), (192, 64), (384, 333), (192, 51200), (192, 20000), (192, 64000), (384, 25600)])
 def test_mlp_fused(dtype, c, m):
