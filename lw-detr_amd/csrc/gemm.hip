@@ -72,7 +72,7 @@ __device__ __forceinline__ void store_run(T* dst, const float* x, int cnt, bool 
 // (ROW orientation: stage[row * (BN + 4) + col]; COL orientation (HEADS_T): stage[col * 68 + row]), is finished by all
 // NTHR threads of the workgroup in runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores; the
 // mode / activation logic lives in a small loop instead of being replicated per accumulator register.
-template <typename T, int BN, int NTHR>
+template <typename T, int BN, int NTHR, int FAST_GROUP = 2>   // FAST_GROUP: sweeps the fast path keeps in flight (registers)
 __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
                                                 const float* stage, long mbase, int n0) {
     typedef typename Vec<T>::v8 V8;
@@ -106,6 +106,69 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                 const long coff = col_offset(sg, nl);
                 const int act = sg.act;
                 const float scale = sg.scale;
+                // Fast path (workgroup-uniform test): all 64 rows exist, whole 16-byte runs, no masks / second destination,
+                // separable LINEAR / HEADS addressing. Straight-line code - the stage reads and residual loads of all
+                // sweeps are issued together, then the arithmetic, then the stores; the general loop below branches on mode,
+                // masks and alignment in every sweep, which serialises the sweeps behind each other's memory latency
+                // (measured on the 256 x 256 tile kernel: 9-12 us of epilogue per tile).
+                constexpr int ITS = 64 / RSTEP;
+                const bool fast = 64 % RSTEP == 0 && mbase + 64 <= d.M && !sg.rowmask && !out2 && (n_end - n0) % 8 == 0 &&
+                                  (sg.mode == LWDETR_OUT_LINEAR || sg.mode == LWDETR_OUT_HEADS) && sg.ldo % 8 == 0 &&
+                                  ((size_t)out & 15) == 0 && (sg.mode == LWDETR_OUT_LINEAR || sg.p1 % 8 == 0) &&
+                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0 && sg.n_begin % 8 == 0));
+                if (fast) {
+                    constexpr int G = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
+                    auto finish_all = [&](auto act_tag) {
+                        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll 1
+                        for (int it0 = 0; it0 < ITS; it0 += G) {
+                            f32x4 a0[G], a1[G];
+                            V8 rv[G];
+                            long ro[G];
+#pragma unroll
+                            for (int g = 0; g < G; ++g) {
+                                const int row = tid / CPRW + (it0 + g) * RSTEP;
+                                const long m = mbase + row;
+                                if (sg.mode == LWDETR_OUT_LINEAR) ro[g] = m * sg.ldo;
+                                else { const int b = (int)(m / sg.p0), t = (int)(m - (long)b * sg.p0); ro[g] = ((long)b * sg.p2 * sg.p0 + t) * sg.p1; }
+                                a0[g] = *(const f32x4*)(stage + row * SLD + col);
+                                a1[g] = *(const f32x4*)(stage + row * SLD + col + 4);
+                            }
+                            if (res) {
+#pragma unroll
+                                for (int g = 0; g < G; ++g) {
+                                    const long m = mbase + tid / CPRW + (it0 + g) * RSTEP;
+                                    rv[g] = *(const V8*)(res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl);
+                                }
+                            }
+#pragma unroll
+                            for (int g = 0; g < G; ++g) {
+                                float x[8];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { x[e] = a0[g][e] + bv[e]; x[4 + e] = a1[g][e] + bv[4 + e]; }
+                                if (ACT != ACT_NONE) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) x[e] = act_apply<T>(x[e], ACT);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) x[e] = x[e] * scale * gv[e];
+                                if (res) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(rv[g][e]);
+                                }
+                                V8 o;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(x[e]);
+                                *(V8*)(out + ro[g] + coff) = o;
+                            }
+                        }
+                    };
+                    if (act == ACT_NONE) finish_all(std::integral_constant<int, ACT_NONE>{});
+                    else if (act == ACT_GELU) finish_all(std::integral_constant<int, ACT_GELU>{});
+                    else if (act == ACT_SILU) finish_all(std::integral_constant<int, ACT_SILU>{});
+                    else finish_all(std::integral_constant<int, ACT_RELU>{});
+                    return;
+                }
 #pragma unroll
                 for (int it = 0; it < (64 + RSTEP - 1) / RSTEP; ++it) {
                     const int row = tid / CPRW + it * RSTEP;
@@ -659,6 +722,25 @@ __global__ __launch_bounds__(256) void gemm_apanel_kernel(const lwdetr_gemm_desc
 #ifndef LWDETR_BIG_VARIANT
 #define LWDETR_BIG_VARIANT 0
 #endif
+#ifndef LWDETR_BIG_SCHED
+#define LWDETR_BIG_SCHED 0
+#endif
+#ifndef LWDETR_BIG_PIPE
+#define LWDETR_BIG_PIPE 1
+#endif
+#ifndef LWDETR_BIG_EPI
+#define LWDETR_BIG_EPI 1          // 1 = epilogue passes of 128 / 256 rows (0: four 64-row passes, round 1 - tuning / A-B)
+#endif
+// Phase timing for kernel tuning (tools/big_timing.py builds a private copy with -DLWDETR_BIG_TIMING=<workgroup>; never in
+// the product): per wave of that workgroup, 10 ns ticks spent in the vmcnt wait, the stage barrier, the MFMA chunks, the
+// epilogue, and the whole kernel.
+#ifdef LWDETR_BIG_TIMING
+__device__ unsigned long long g_big_timing[8][8];
+extern "C" int lwdetr_debug_big_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_timing), sizeof(g_big_timing)) == hipSuccess ? 0 : 1;
+}
+#define BIG_NOW() __builtin_amdgcn_s_memrealtime()
+#endif
 template <typename T> struct Mma32;
 template <> struct Mma32<f16> {
     static __device__ __forceinline__ f32x16 k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -705,30 +787,29 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
     // they cost ~100 issue cycles each with both waves of a SIMD stalled behind them (kb64: 8 pieces per wave and stage).
     const int prow = lane / SLOTS, pslot = lane % SLOTS;
     auto key_of = [](int row) { return KB == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
-    const T* psrc[PER_STAGE]; int pstep[PER_STAGE];
+    // Piece kk of an operand covers tile rows RP (wave + 8 kk) + prow: 8 RP rows further per piece, and the swizzle key of
+    // those rows does not depend on kk (8 RP is a multiple of the key period) - so a lane keeps ONE base offset per operand
+    // and adds the wave-uniform piece / stage displacement when it issues (the round-1 kernel kept a pointer and a step per
+    // piece: 24 registers the accumulators need).
+    const int row0 = RP * wave + prow;
+    const int swz = (pslot ^ key_of(row0)) * EPC;
+    static_assert((8 * RP) % 16 == 0, "piece stride must preserve the swizzle key");
+    const long a_row0 = m0 + row0, w_row0 = (long)n0 + row0;
+    const long a_off0 = a_row0 * d.lda + swz, w_off0 = w_row0 * (long)d.K + swz;
     // implicit-GEMM 3x3 view (AMODE CONV3x3): A row = output pixel (b, y, x); stage k0 reads channels k0 % Cin .. of the input
     // pixel (y s + tap / 3 - 1, x s + tap % 3 - 1), tap = k0 / Cin (zero page outside the image). The shifted source row
-    // only changes with the tap - every Cin / KB stages - so its address is cached per piece (gemm_dma_kernel does the same).
-    int cv_b[A_MY], cv_y[A_MY], cv_x[A_MY], cv_tap[A_MY]; const T* cv_src[A_MY];
+    // only changes with the tap - every Cin / KB stages - so its address is cached per piece (gemm_dma_kernel does the same);
+    // the pixel coordinates are packed into one register per piece (b: 12 bits, y: 10, x: 10; -1 = row past M).
+    int cv_pix[A_MY]; const T* cv_src[A_MY];
+    if (AMODE == LWDETR_A_CONV3x3) {
 #pragma unroll
-    for (int k = 0; k < PER_STAGE; ++k) {
-        const bool is_a = k < A_MY;
-        const int row = RP * (wave + 8 * (is_a ? k : k - A_MY)) + prow;
-        const long gr = (is_a ? m0 : (long)n0) + row;
-        const bool ok = gr < (is_a ? d.M : (long)d.N);
-        if (AMODE == LWDETR_A_CONV3x3 && is_a) {
+        for (int k = 0; k < A_MY; ++k) {
+            const long gr = a_row0 + 8 * RP * k;
             const int hw = d.conv_hout * d.conv_wout;
-            const int b = (int)(gr / hw), r = (int)(gr - (long)b * hw);
-            if (k < A_MY) {
-                cv_b[k < A_MY ? k : 0] = ok ? b : -1; cv_y[k < A_MY ? k : 0] = r / d.conv_wout;
-                cv_x[k < A_MY ? k : 0] = r - (r / d.conv_wout) * d.conv_wout; cv_tap[k < A_MY ? k : 0] = -1; cv_src[k < A_MY ? k : 0] = nullptr;
-            }
-            psrc[k] = zero + (pslot ^ key_of(row)) * 0; pstep[k] = (pslot ^ key_of(row)) * EPC;      // pstep: this lane's channel offset
-            continue;
+            const int b = (int)(gr / hw), r = (int)(gr - (long)b * hw), y = r / d.conv_wout, x = r - y * d.conv_wout;
+            cv_pix[k] = gr < d.M ? (b << 20) | (y << 10) | x : -1;
+            cv_src[k] = nullptr;
         }
-        const T* base = is_a ? A + gr * d.lda : W + gr * (long)d.K;
-        psrc[k] = ok ? base + (pslot ^ key_of(row)) * EPC : zero;
-        pstep[k] = ok ? KB : 0;
     }
     const int nk = d.K / KB;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)big_smem;
@@ -738,25 +819,42 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
         const bool is_a = k < A_MY;
         const unsigned dst = lds0 + (unsigned)((kt % NST) * STAGE + (is_a ? 0 : BM * KB)) * (unsigned)sizeof(T) + wave_off +
                              (unsigned)(8 * (is_a ? k : k - A_MY) * 64 * EPC * (int)sizeof(T));
+        const int kk = is_a ? k : k - A_MY;
         const T* src;
         if (AMODE == LWDETR_A_CONV3x3 && is_a) {
-            const int kk = k < A_MY ? k : 0;
-            const int k0 = kt * KB, tap = k0 / d.conv_cin;               // wave-uniform
-            if (tap != cv_tap[kk]) {
-                cv_tap[kk] = tap;
-                const int iy = cv_y[kk] * d.conv_stride + tap / 3 - 1, ix = cv_x[kk] * d.conv_stride + tap % 3 - 1;
-                cv_src[kk] = (cv_b[kk] >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp)
-                                 ? A + tok_encode(cv_b[kk], iy, ix, d.a_tok) * d.lda + d.a_col0 + pstep[k] : nullptr;
+            const int k0 = kt * KB, tap = k0 / d.conv_cin, c0 = k0 - tap * d.conv_cin;      // wave-uniform
+            if (c0 == 0) {                 // first stage of a tap (stages reach a piece in order): new source pixel
+                const int pix = cv_pix[kk], b = pix >> 20, y = (pix >> 10) & 1023, x = pix & 1023;
+                const int iy = y * d.conv_stride + tap / 3 - 1, ix = x * d.conv_stride + tap % 3 - 1;
+                cv_src[kk] = (pix >= 0 && iy >= 0 && iy < d.a_tok.Hp && ix >= 0 && ix < d.a_tok.Wp)
+                                 ? A + tok_encode(b, iy, ix, d.a_tok) * d.lda + d.a_col0 + swz : nullptr;
             }
-            src = (kt < nk && cv_src[kk]) ? cv_src[kk] + (k0 - tap * d.conv_cin) : zero;
+            src = (kt < nk && cv_src[kk]) ? cv_src[kk] + c0 : zero;
         } else {
-            src = kt < nk ? psrc[k] + (long)kt * pstep[k] : zero;
+            const long disp = (long)(8 * RP * kk) * (is_a ? (long)d.lda : (long)d.K) + (long)kt * KB;       // wave-uniform
+            const bool ok = kt < nk && (is_a ? a_row0 + 8 * RP * kk < d.M : w_row0 + 8 * RP * kk < (long)d.N);
+            src = ok ? (is_a ? A + a_off0 : W + w_off0) + disp : zero;
         }
         const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
 #if LWDETR_BIG_VARIANT & 1
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" :: "s"(m0v), "v"(src) : "memory");
 #else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
+#endif
+    };
+
+    // Which 16-deep chunk of step kt issues piece k of stage kt + NST - 1. The step cannot end before its last-issued piece
+    // has landed (step period = max(MFMA time, issue offset + memory latency)), so the schedule front-loads: the A pieces
+    // - activations, partly from HBM, the long latency - go out during chunk 0, the W pieces (L2-resident weights) after them.
+    // LWDETR_BIG_SCHED (tuning): 0 = round-robin over all chunks (round 1), 1 = A in chunk 0, W in chunk 1, 2 = A in chunk 0,
+    // W over chunks 1-2.
+    auto piece_chunk = [](int k) {
+#if LWDETR_BIG_SCHED == 0
+        return k % KC;
+#elif LWDETR_BIG_SCHED == 1
+        return k < A_MY ? 0 : (KC > 1 ? 1 : 0);
+#else
+        return k < A_MY ? 0 : (KC > 2 ? 1 + (k - A_MY) * 2 / B_MY : KC - 1);
 #endif
     };
 
@@ -784,13 +882,108 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+#if LWDETR_BIG_PIPE
+        // Software pipeline over (stage, 16-deep chunk) slots. Slot (kt, c) multiplies chunk c of stage kt out of one fragment
+        // buffer while it reads the NEXT chunk - (kt, c + 1), or (kt + 1, 0) in the last slot - into the other one, one
+        // ds_read after each MFMA (the LDS queue sees a steady trickle instead of 8 waves x 6 reads right after a barrier, and
+        // no chunk starts on fragments that were requested just before it). The stage barrier sits in FRONT of the last slot
+        // of a stage: by then every wave holds the last fragments of stage kt in registers, so the buffer of stage kt is free
+        // for the A pieces of stage kt + NST (issued in that slot; the W pieces of a stage follow one slot later), and stage
+        // kt + 1 - whose first chunk the slot reads - must have landed: A pieces have had a whole step, W pieces KC - 1 slots.
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_)
 #pragma unroll
             for (int k = 0; k < PER_STAGE; ++k) issue_piece(s_, k);
+#pragma unroll
+        for (int k = 0; k < A_MY; ++k) issue_piece(NST - 1, k);
+#ifdef LWDETR_BIG_TIMING
+        unsigned long long tt_wait = 0, tt_bar = 0, tt_mma = 0;
+        const unsigned long long tt_start = BIG_NOW();
+#endif
+        V8 xf[2][TM], wf[2][TN];
+        wait_vmcnt<(NST - 2) * PER_STAGE + A_MY>();        // stage 0 has landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                      // ... and everybody's
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[0][i] = *(const V8*)(smem + arow + i * 32 * KB + pofs[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[0][j] = *(const V8*)(smem + BM * KB + brow + j * 32 * KB + pofs[0]);
         for (int kt = 0; kt < nk; ++kt) {
+            const T* As = smem + (kt % NST) * STAGE;
+            const T* An = smem + ((kt + 1) % NST) * STAGE;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                constexpr int NM = TN * TM, NR = TM + TN;
+                const bool last = c == KC - 1;
+                if (last) {
+#ifdef LWDETR_BIG_TIMING
+                    const unsigned long long ta = BIG_NOW();
+#endif
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last fragments of stage kt are in registers
+                    wait_vmcnt<(NST - 2) * PER_STAGE>();                 // stage kt + 1 has landed (this wave's pieces)
+#ifdef LWDETR_BIG_TIMING
+                    const unsigned long long tb = BIG_NOW();
+#endif
+                    __builtin_amdgcn_s_barrier();
+#ifdef LWDETR_BIG_TIMING
+                    tt_wait += tb - ta; tt_bar += BIG_NOW() - tb;
+#endif
+                }
+                const T* Ar = last ? An : As;
+                const T* Br = Ar + BM * KB;
+                const int po = pofs[(c + 1) % KC];
+                const int nb = (c + 1) & 1, cb = c & 1;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int idx = 0; idx < (NM > NR ? NM : NR); ++idx) {
+                    if (idx < NM) {
+                        const int j = idx / TM, i = idx % TM;
+#if LWDETR_BIG_VARIANT & 32       // ablation (timing only): no MFMAs
+                        asm volatile("" : "+v"(acc[j][i]) : "v"(xf[cb][i]), "v"(wf[cb][j]));
+#else
+                        acc[j][i] = COL ? Mma32<T>::k16(xf[cb][i], wf[cb][j], acc[j][i]) : Mma32<T>::k16(wf[cb][j], xf[cb][i], acc[j][i]);
+#endif
+                    }
+                    if (idx < NR) {      // read order = the order the next slot's MFMAs want them: x0, w0, x1 .. x(TM-1), w1 ..
+                        if (idx == 0) xf[nb][0] = *(const V8*)(Ar + arow + po);
+                        else if (idx == 1) wf[nb][0] = *(const V8*)(Br + brow + po);
+                        else if (idx < TM + 1) xf[nb][idx - 1] = *(const V8*)(Ar + arow + (idx - 1) * 32 * KB + po);
+                        else wf[nb][idx - TM] = *(const V8*)(Br + brow + (idx - TM) * 32 * KB + po);
+                    }
+#if !(LWDETR_BIG_VARIANT & 8)         // ablation (timing only): 8 = no DMA inside the loop
+                    if (last && idx < A_MY) issue_piece(kt + NST, idx);                  // A pieces of stage kt + NST
+                    if (c == 0 && idx < B_MY) issue_piece(kt + NST - 1, A_MY + idx);     // W pieces of stage kt + NST - 1
+#endif
+#if !(LWDETR_BIG_VARIANT & 4)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+                static_assert(A_MY <= (NM > NR ? NM : NR) && B_MY <= (NM > NR ? NM : NR), "one DMA piece per MFMA at most");
+            }
+        }
+#ifdef LWDETR_BIG_TIMING
+        tt_mma = BIG_NOW() - tt_start - tt_wait - tt_bar;
+#endif
+#else
+#pragma unroll
+        for (int s_ = 0; s_ < NST - 1; ++s_)
+#pragma unroll
+            for (int k = 0; k < PER_STAGE; ++k) issue_piece(s_, k);
+#ifdef LWDETR_BIG_TIMING
+        unsigned long long tt_wait = 0, tt_bar = 0, tt_mma = 0;
+        const unsigned long long tt_start = BIG_NOW();
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+#ifdef LWDETR_BIG_TIMING
+            const unsigned long long ta = BIG_NOW();
+            wait_vmcnt<(NST - 2) * PER_STAGE>();
+            const unsigned long long tb = BIG_NOW();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long tc = BIG_NOW();
+            tt_wait += tb - ta; tt_bar += tc - tb;
+#else
             wait_vmcnt<(NST - 2) * PER_STAGE>();           // stage kt has landed (this wave's pieces) ...
             __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody has also left stage kt - 1
+#endif
             const T* As = smem + (kt % NST) * STAGE;
             const T* Bs = As + BM * KB;
             V8 xf[2][TM], wf[2][TN];                       // fragments of chunk c + 1 are read while chunk c multiplies
@@ -807,7 +1000,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
                     for (int j = 0; j < TN; ++j) wf[(c + 1) & 1][j] = *(const V8*)(Bs + brow + j * 32 * KB + pofs[c + 1]);
                 }
 #pragma unroll
-                for (int k = c; k < PER_STAGE; k += KC) issue_piece(kt + NST - 1, k);   // refill the buffer stage kt - 1 used
+                for (int k = 0; k < PER_STAGE; ++k)        // refill the buffer stage kt - 1 used
+                    if (piece_chunk(k) == c) issue_piece(kt + NST - 1, k);
 #if !(LWDETR_BIG_VARIANT & 4)
                 __builtin_amdgcn_sched_barrier(0);   // reads of chunk c + 1 and the DMA issue stay AHEAD of chunk c's MFMAs
 #endif
@@ -824,32 +1018,72 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
+#ifdef LWDETR_BIG_TIMING
+            tt_mma += BIG_NOW() - tc;
+#endif
         }
+#endif
+#ifdef LWDETR_BIG_TIMING
+        const unsigned long long tt_loop = BIG_NOW();
+#endif
         wait_vmcnt<0>();        // the dummy tail pieces (hipcc does not know about them)
         __syncthreads();        // drains the dummy tail pieces and the last fragment reads before LDS is re-used
-        // ---- epilogue: passes of 64 rows through the f32 stage area (aliases the ring), finished by all 512 threads.
+#ifdef LWDETR_BIG_TIMING
+        unsigned long long te_stage = 0, te_fin = 0, te_sync = 0; const unsigned long long te_drain = BIG_NOW();
+#endif
+        // ---- epilogue: 64-row blocks through the f32 stage area (aliases the ring), finished by all 512 threads. A pass
+        // stages EPI_SLOTS blocks at once - chosen so that every wave has tiles in every pass (block b of the tile belongs
+        // to pass b % EPI_PASSES, stage slot b / EPI_PASSES) - and is bracketed by one pair of workgroup barriers: two
+        // passes for BN = 256 / 192, one for BN = 128 (round 1: four passes of one block, half or a quarter of the waves
+        // staging in each: 9-12 us per tile, a third of a K = 768 tile's time; a register-direct epilogue - permlane32
+        // swaps to 16-byte runs, no LDS - measured slower, 14-19 us: its stores touch 32 rows x 32 bytes per instruction).
         // 32x32 accumulator: register 4 q + r of lane (c = lane & 31, hi) is element (row 8 q + 4 hi + r, column c) of D.
+        constexpr int EPI_PASSES = LWDETR_BIG_EPI ? (BN == 128 ? 1 : 2) : 4, EPI_SLOTS = 4 / EPI_PASSES;
 #pragma unroll 1
-        for (int pass = 0; pass < BM / 64; ++pass) {
+        for (int pass = 0; pass < EPI_PASSES; ++pass) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if (wm * (WM / 64) + (i >> 1) != pass) continue;        // wave-uniform: this tile's rows belong to the pass
+                const int blk = wm * (WM / 64) + (i >> 1);
+                if (blk % EPI_PASSES != pass) continue;                 // wave-uniform: this tile's rows belong to the pass
                 const int ii = i & 1;
+                float* sb = stg + (blk / EPI_PASSES) * (COL ? BN * SLD_T : 64 * SLD);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 v = {acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]};
                         if (!COL)    // lane: row ii * 32 + (lane & 31), columns wn WN + 32 j + 8 q + 4 hi .. + 3
-                            *(f32x4*)(stg + (ii * 32 + m) * SLD + wn * WN + j * 32 + q * 8 + h * 4) = v;
+                            *(f32x4*)(sb + (ii * 32 + m) * SLD + wn * WN + j * 32 + q * 8 + h * 4) = v;
                         else         // lane: column wn WN + 32 j + (lane & 31), rows ii * 32 + 8 q + 4 hi .. + 3
-                            *(f32x4*)(stg + (wn * WN + j * 32 + m) * SLD_T + ii * 32 + q * 8 + h * 4) = v;
+                            *(f32x4*)(sb + (wn * WN + j * 32 + m) * SLD_T + ii * 32 + q * 8 + h * 4) = v;
                     }
             }
+#ifdef LWDETR_BIG_TIMING
+            const unsigned long long t0_ = BIG_NOW();
+#endif
             __syncthreads();
-            epilogue_finish<T, BN, 512>(d, sg, COL, stg, m0 + pass * 64, n0);
+#ifdef LWDETR_BIG_TIMING
+            const unsigned long long t1_ = BIG_NOW();
+#endif
+#pragma unroll 1
+            for (int slot = 0; slot < EPI_SLOTS; ++slot)       // not unrolled: the accumulators of the later passes are still live
+                epilogue_finish<T, BN, 512, 4>(d, sg, COL, stg + slot * (COL ? BN * SLD_T : 64 * SLD), m0 + (slot * EPI_PASSES + pass) * 64, n0);
+#ifdef LWDETR_BIG_TIMING
+            const unsigned long long t2_ = BIG_NOW();
+#endif
             __syncthreads();
+#ifdef LWDETR_BIG_TIMING
+            te_stage += t1_ - t0_; te_fin += t2_ - t1_; te_sync += BIG_NOW() - t2_;
+#endif
         }
+#ifdef LWDETR_BIG_TIMING
+        if (blockIdx.x == LWDETR_BIG_TIMING && lane == 0) {
+            const unsigned long long te = BIG_NOW();
+            unsigned long long* o = g_big_timing[wave];
+            o[0] = tt_wait; o[1] = tt_bar; o[2] = tt_mma; o[3] = te - tt_loop; o[4] = te - tt_start; o[5] = nk;
+            o[6] = (te_drain - tt_loop) | (te_stage << 16) | (te_fin << 32) | (te_sync << 48);     // 10 ns ticks, 16 bits each
+        }
+#endif
     };
     if (col_orient) body(std::true_type{});
     else body(std::false_type{});
@@ -858,7 +1092,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
 template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
 int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     constexpr size_t ring = (size_t)NST * (256 + BN) * KB * sizeof(T);
-    constexpr size_t stg = (size_t)(64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
+    constexpr size_t stg = (size_t)(LWDETR_BIG_EPI ? (BN == 128 ? 4 : 2) : 1) * (64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
     constexpr size_t lds = ring > stg ? ring : stg;
     static bool done = false;
     if (!done) {
@@ -886,7 +1120,8 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
         static const char* env = getenv("LWDETR_GEMM_BIG");
         const int mode = g_big_mode >= 0 ? g_big_mode : (env ? atoi(env) : 1);
         if (!mode || d.A2 || d.K % 64 != 0 || d.N < 128) return LWDETR_OK;
-        if (AMODE == LWDETR_A_CONV3x3 && (d.conv_cin % 64 != 0 || d.a_col0 % 8 != 0)) return LWDETR_OK;
+        if (AMODE == LWDETR_A_CONV3x3 && (d.conv_cin % 64 != 0 || d.a_col0 % 8 != 0 || d.conv_hout > 1024 || d.conv_wout > 1024 ||
+                                          d.M / ((long)d.conv_hout * d.conv_wout) >= 2048)) return LWDETR_OK;   // packed pixel coordinates
         // column tile: 256 where N and the segment boundaries allow; 192 for N <= 192 (the 3x3 convolutions of the C2f blocks:
         // ONE column tile instead of two half-empty 128-wide ones); else 128. (Measured: N = 384 as 2 x 192 is 5-20 % slower
         // than 3 x 128 - fewer, fatter tiles on a 2-deep ring - and N = 1152 ties.)
