@@ -215,23 +215,50 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                 }
             }
         } else {
-            // HEADS_T: out[((b*heads+h)*hd+dd)*Tp + t]: runs of 4 consecutive tokens of one output column
+            // HEADS_T: out[((b*heads+h)*hd+dd)*Tp + t]: runs of 4 consecutive tokens of one output column. A thread keeps
+            // its token run for the whole sweep when NTHR is a multiple of the 16 runs of a column (image index and token
+            // offset - two divisions - are computed once; round 1 redid them, in 64 bits, for every run).
             constexpr int RPC = 64 / 4;
-#pragma unroll 1
-            for (int c = tid; c < BN * RPC; c += NTHR) {
-                const int coln = c / RPC, row = (c - coln * RPC) * 4;
+            if (NTHR % RPC == 0) {
+                const int row = (tid % RPC) * 4;
                 const long m = mbase + row;
-                const int n = n0 + coln;
-                if (m >= d.M || n >= n_end) continue;
-                const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
-                const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
-                const float bias = sg.bias ? sg.bias[nl] : 0.f;
-                float x[4];
+                if (m < d.M) {
+                    const int cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
+                    const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
+                    T* obase = out + (long)b * sg.p2 * sg.p1 * sg.p0 + tk;
+                    const bool al = (((size_t)obase | ((size_t)sg.p0 * sizeof(T))) & (4 * sizeof(T) - 1)) == 0;
+                    const int act = sg.act;
+                    const float scale = sg.scale;
+#pragma unroll 4
+                    for (int coln = tid / RPC; coln < BN; coln += NTHR / RPC) {
+                        const int n = n0 + coln;
+                        if (n >= n_end) break;
+                        const int nl = n - sg.n_begin;
+                        const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
+                        const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                        float x[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, sg.act) * sg.scale;
-                const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
-                T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
-                store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
+                        for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, act) * scale;
+                        store_run<T, 4>(obase + (long)nl * sg.p0, x, cnt, al);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int c = tid; c < BN * RPC; c += NTHR) {
+                    const int coln = c / RPC, row = (c - coln * RPC) * 4;
+                    const long m = mbase + row;
+                    const int n = n0 + coln;
+                    if (m >= d.M || n >= n_end) continue;
+                    const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
+                    const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
+                    const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, sg.act) * sg.scale;
+                    const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
+                    T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
+                    store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
+                }
             }
         }
     }
@@ -728,6 +755,9 @@ __global__ __launch_bounds__(256) void gemm_apanel_kernel(const lwdetr_gemm_desc
 #ifndef LWDETR_BIG_PIPE
 #define LWDETR_BIG_PIPE 1
 #endif
+#ifndef LWDETR_BIG_RPM
+#define LWDETR_BIG_RPM 1
+#endif
 #ifndef LWDETR_BIG_EPI
 #define LWDETR_BIG_EPI 1          // 1 = epilogue passes of 128 / 256 rows (0: four 64-row passes, round 1 - tuning / A-B)
 #endif
@@ -943,11 +973,15 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
                         acc[j][i] = COL ? Mma32<T>::k16(xf[cb][i], wf[cb][j], acc[j][i]) : Mma32<T>::k16(wf[cb][j], xf[cb][i], acc[j][i]);
 #endif
                     }
-                    if (idx < NR) {      // read order = the order the next slot's MFMAs want them: x0, w0, x1 .. x(TM-1), w1 ..
-                        if (idx == 0) xf[nb][0] = *(const V8*)(Ar + arow + po);
-                        else if (idx == 1) wf[nb][0] = *(const V8*)(Br + brow + po);
-                        else if (idx < TM + 1) xf[nb][idx - 1] = *(const V8*)(Ar + arow + (idx - 1) * 32 * KB + po);
-                        else wf[nb][idx - TM] = *(const V8*)(Br + brow + (idx - TM) * 32 * KB + po);
+                    // read order = the order the next slot's MFMAs want them: x0, w0, x1 .. x(TM-1), w1 ..; LWDETR_BIG_RPM of
+                    // them after each MFMA (2: all reads are out by the third MFMA - one or two MFMA slots more latency budget)
+#pragma unroll
+                    for (int rr = idx * LWDETR_BIG_RPM; rr < (idx + 1) * LWDETR_BIG_RPM; ++rr) {
+                        if (rr >= NR) continue;
+                        if (rr == 0) xf[nb][0] = *(const V8*)(Ar + arow + po);
+                        else if (rr == 1) wf[nb][0] = *(const V8*)(Br + brow + po);
+                        else if (rr < TM + 1) xf[nb][rr - 1] = *(const V8*)(Ar + arow + (rr - 1) * 32 * KB + po);
+                        else wf[nb][rr - TM] = *(const V8*)(Br + brow + (rr - TM) * 32 * KB + po);
                     }
 #if !(LWDETR_BIG_VARIANT & 8)         // ablation (timing only): 8 = no DMA inside the loop
                     if (last && idx < A_MY) issue_piece(kt + NST, idx);                  // A pieces of stage kt + NST
