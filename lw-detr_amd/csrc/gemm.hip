@@ -1160,6 +1160,8 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
         // ONE column tile instead of two half-empty 128-wide ones); else 128. (Measured: N = 384 as 2 x 192 is 5-20 % slower
         // than 3 x 128 - fewer, fatter tiles on a 2-deep ring - and N = 1152 ties.)
         int bn = d.N % 256 == 0 || d.N > 512 ? 256 : (d.N <= 192 ? 192 : 128);
+        static const char* bn_env = getenv("LWDETR_GEMM_BIG_BN");       // tuning: force the column tile where legal
+        if (bn_env) bn = atoi(bn_env);
         for (int s = 0; s < d.nseg; ++s)
             if (d.seg[s].n_begin % bn != 0) bn = 128;
         for (int s = 0; s < d.nseg; ++s) if (d.seg[s].n_begin % bn != 0) return LWDETR_OK;
