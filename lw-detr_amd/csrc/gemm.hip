@@ -744,22 +744,10 @@ __global__ __launch_bounds__(256) void gemm_apanel_kernel(const lwdetr_gemm_desc
 // 375 TFLOP/s with 64 x 64, 430 with 128 x 128). LDS swizzle for the 32-row fragments (lane -> row = lane & 31, 16-byte
 // k-slot 2 kc + (lane >> 5)): slot ^= (row >> 2) & 3 at KB = 32, (row >> 1) & 7 at KB = 64 - conflict-free for the 16-lane
 // ds_read_b128 service groups (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}).
-// Tuning builds (tools/gemm_big_variants.sh, -DLWDETR_BIG_VARIANT=bits): 1 = nt policy on the DMA, 2 = s_setprio(1) around
-// the MFMA groups, 4 = no sched_barrier between the read / DMA block and the MFMAs. The product is built with 0.
+// Ablation builds (-DLWDETR_BIG_VARIANT=bits, timing only - results are wrong with 8 / 32): 4 = no sched_barrier pins in the
+// loop, 8 = no DMA inside the loop, 32 = no MFMAs (profiles/r2g_gemm_big_pipeline.txt). The product is built with 0.
 #ifndef LWDETR_BIG_VARIANT
 #define LWDETR_BIG_VARIANT 0
-#endif
-#ifndef LWDETR_BIG_SCHED
-#define LWDETR_BIG_SCHED 0
-#endif
-#ifndef LWDETR_BIG_PIPE
-#define LWDETR_BIG_PIPE 1
-#endif
-#ifndef LWDETR_BIG_RPM
-#define LWDETR_BIG_RPM 1
-#endif
-#ifndef LWDETR_BIG_EPI
-#define LWDETR_BIG_EPI 1          // 1 = epilogue passes of 128 / 256 rows (0: four 64-row passes, round 1 - tuning / A-B)
 #endif
 // Phase timing for kernel tuning (tools/big_timing.py builds a private copy with -DLWDETR_BIG_TIMING=<workgroup>; never in
 // the product): per wave of that workgroup, 10 ns ticks spent in the vmcnt wait, the stage barrier, the MFMA chunks, the
@@ -866,26 +854,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
             src = ok ? (is_a ? A + a_off0 : W + w_off0) + disp : zero;
         }
         const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
-#if LWDETR_BIG_VARIANT & 1
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" :: "s"(m0v), "v"(src) : "memory");
-#else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
-#endif
-    };
-
-    // Which 16-deep chunk of step kt issues piece k of stage kt + NST - 1. The step cannot end before its last-issued piece
-    // has landed (step period = max(MFMA time, issue offset + memory latency)), so the schedule front-loads: the A pieces
-    // - activations, partly from HBM, the long latency - go out during chunk 0, the W pieces (L2-resident weights) after them.
-    // LWDETR_BIG_SCHED (tuning): 0 = round-robin over all chunks (round 1), 1 = A in chunk 0, W in chunk 1, 2 = A in chunk 0,
-    // W over chunks 1-2.
-    auto piece_chunk = [](int k) {
-#if LWDETR_BIG_SCHED == 0
-        return k % KC;
-#elif LWDETR_BIG_SCHED == 1
-        return k < A_MY ? 0 : (KC > 1 ? 1 : 0);
-#else
-        return k < A_MY ? 0 : (KC > 2 ? 1 + (k - A_MY) * 2 / B_MY : KC - 1);
-#endif
     };
 
     int si = 0;
@@ -912,7 +881,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
-#if LWDETR_BIG_PIPE
         // Software pipeline over (stage, 16-deep chunk) slots. Slot (kt, c) multiplies chunk c of stage kt out of one fragment
         // buffer while it reads the NEXT chunk - (kt, c + 1), or (kt + 1, 0) in the last slot - into the other one, one
         // ds_read after each MFMA (the LDS queue sees a steady trickle instead of 8 waves x 6 reads right after a barrier, and
@@ -973,16 +941,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
                         acc[j][i] = COL ? Mma32<T>::k16(xf[cb][i], wf[cb][j], acc[j][i]) : Mma32<T>::k16(wf[cb][j], xf[cb][i], acc[j][i]);
 #endif
                     }
-                    // read order = the order the next slot's MFMAs want them: x0, w0, x1 .. x(TM-1), w1 ..; LWDETR_BIG_RPM of
-                    // them after each MFMA (2: all reads are out by the third MFMA - one or two MFMA slots more latency budget)
-#pragma unroll
-                    for (int rr = idx * LWDETR_BIG_RPM; rr < (idx + 1) * LWDETR_BIG_RPM; ++rr) {
-                        if (rr >= NR) continue;
-                        if (rr == 0) xf[nb][0] = *(const V8*)(Ar + arow + po);
-                        else if (rr == 1) wf[nb][0] = *(const V8*)(Br + brow + po);
-                        else if (rr < TM + 1) xf[nb][rr - 1] = *(const V8*)(Ar + arow + (rr - 1) * 32 * KB + po);
-                        else wf[nb][rr - TM] = *(const V8*)(Br + brow + (rr - TM) * 32 * KB + po);
-                    }
+                    // one fragment read after each MFMA, in the order the next slot's MFMAs want them: x0, w0, x1 .. x(TM-1),
+                    // w1 .. (two or three per MFMA - all reads out by the third MFMA - measured 3-4 % slower: bursts on the LDS queue)
+                    if (idx == 0) xf[nb][0] = *(const V8*)(Ar + arow + po);
+                    else if (idx == 1) wf[nb][0] = *(const V8*)(Br + brow + po);
+                    else if (idx < TM + 1) xf[nb][idx - 1] = *(const V8*)(Ar + arow + (idx - 1) * 32 * KB + po);
+                    else if (idx < NR) wf[nb][idx - TM] = *(const V8*)(Br + brow + (idx - TM) * 32 * KB + po);
 #if !(LWDETR_BIG_VARIANT & 8)         // ablation (timing only): 8 = no DMA inside the loop
                     if (last && idx < A_MY) issue_piece(kt + NST, idx);                  // A pieces of stage kt + NST
                     if (c == 0 && idx < B_MY) issue_piece(kt + NST - 1, A_MY + idx);     // W pieces of stage kt + NST - 1
@@ -995,70 +959,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
             }
         }
 #ifdef LWDETR_BIG_TIMING
-        tt_mma = BIG_NOW() - tt_start - tt_wait - tt_bar;
-#endif
-#else
-#pragma unroll
-        for (int s_ = 0; s_ < NST - 1; ++s_)
-#pragma unroll
-            for (int k = 0; k < PER_STAGE; ++k) issue_piece(s_, k);
-#ifdef LWDETR_BIG_TIMING
-        unsigned long long tt_wait = 0, tt_bar = 0, tt_mma = 0;
-        const unsigned long long tt_start = BIG_NOW();
-#endif
-        for (int kt = 0; kt < nk; ++kt) {
-#ifdef LWDETR_BIG_TIMING
-            const unsigned long long ta = BIG_NOW();
-            wait_vmcnt<(NST - 2) * PER_STAGE>();
-            const unsigned long long tb = BIG_NOW();
-            __builtin_amdgcn_s_barrier();
-            const unsigned long long tc = BIG_NOW();
-            tt_wait += tb - ta; tt_bar += tc - tb;
-#else
-            wait_vmcnt<(NST - 2) * PER_STAGE>();           // stage kt has landed (this wave's pieces) ...
-            __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody has also left stage kt - 1
-#endif
-            const T* As = smem + (kt % NST) * STAGE;
-            const T* Bs = As + BM * KB;
-            V8 xf[2][TM], wf[2][TN];                       // fragments of chunk c + 1 are read while chunk c multiplies
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xf[0][i] = *(const V8*)(As + arow + i * 32 * KB + pofs[0]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wf[0][j] = *(const V8*)(Bs + brow + j * 32 * KB + pofs[0]);
-#pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                if (c + 1 < KC) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) xf[(c + 1) & 1][i] = *(const V8*)(As + arow + i * 32 * KB + pofs[c + 1]);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) wf[(c + 1) & 1][j] = *(const V8*)(Bs + brow + j * 32 * KB + pofs[c + 1]);
-                }
-#pragma unroll
-                for (int k = 0; k < PER_STAGE; ++k)        // refill the buffer stage kt - 1 used
-                    if (piece_chunk(k) == c) issue_piece(kt + NST - 1, k);
-#if !(LWDETR_BIG_VARIANT & 4)
-                __builtin_amdgcn_sched_barrier(0);   // reads of chunk c + 1 and the DMA issue stay AHEAD of chunk c's MFMAs
-#endif
-#if LWDETR_BIG_VARIANT & 2
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)     // ROW: D[n][m], lane holds 4 consecutive n of one row m; COL: D[m][n]
-                        acc[j][i] = COL ? Mma32<T>::k16(xf[c & 1][i], wf[c & 1][j], acc[j][i])
-                                        : Mma32<T>::k16(wf[c & 1][j], xf[c & 1][i], acc[j][i]);
-#if LWDETR_BIG_VARIANT & 2
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
-#ifdef LWDETR_BIG_TIMING
-            tt_mma += BIG_NOW() - tc;
-#endif
-        }
-#endif
-#ifdef LWDETR_BIG_TIMING
         const unsigned long long tt_loop = BIG_NOW();
+        tt_mma = tt_loop - tt_start - tt_wait - tt_bar;
 #endif
         wait_vmcnt<0>();        // the dummy tail pieces (hipcc does not know about them)
         __syncthreads();        // drains the dummy tail pieces and the last fragment reads before LDS is re-used
@@ -1072,7 +974,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
         // staging in each: 9-12 us per tile, a third of a K = 768 tile's time; a register-direct epilogue - permlane32
         // swaps to 16-byte runs, no LDS - measured slower, 14-19 us: its stores touch 32 rows x 32 bytes per instruction).
         // 32x32 accumulator: register 4 q + r of lane (c = lane & 31, hi) is element (row 8 q + 4 hi + r, column c) of D.
-        constexpr int EPI_PASSES = LWDETR_BIG_EPI ? (BN == 128 ? 1 : 2) : 4, EPI_SLOTS = 4 / EPI_PASSES;
+        constexpr int EPI_PASSES = BN == 128 ? 1 : 2, EPI_SLOTS = 4 / EPI_PASSES;
 #pragma unroll 1
         for (int pass = 0; pass < EPI_PASSES; ++pass) {
 #pragma unroll
@@ -1126,7 +1028,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
 template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
 int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     constexpr size_t ring = (size_t)NST * (256 + BN) * KB * sizeof(T);
-    constexpr size_t stg = (size_t)(LWDETR_BIG_EPI ? (BN == 128 ? 4 : 2) : 1) * (64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
+    constexpr size_t stg = (size_t)(BN == 128 ? 4 : 2) * (64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
     constexpr size_t lds = ring > stg ? ring : stg;
     static bool done = false;
     if (!done) {

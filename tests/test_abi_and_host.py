@@ -105,6 +105,29 @@ def test_convx_folding_and_gemm_weight_layouts():
     assert torch.allclose(y, F.conv_transpose2d(x, wd, stride=2), atol=1e-5)
 
 
+def test_mlp_weight_packing_reproduces_the_unpacked_math():
+    """Host packing for the block kernel / decoder FFN: LayerNorm affine folded into fc1, fc2 chunk-major in MFMA k-slot
+    order; with ln_w = None (decoder FFN) fc1 is untouched. Any hidden size that is a multiple of 32 (not only 4 C)."""
+    from lwdetr_amd import kernels as K
+    g = torch.Generator().manual_seed(1)
+    for c, hid, with_ln in [(64, 256, True), (64, 96, False), (32, 64, False)]:
+        w1, b1 = torch.randn(hid, c, generator=g), torch.randn(hid, generator=g)
+        w2 = torch.randn(c, hid, generator=g)
+        lw, lb = (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)) if with_ln else (None, None)
+        w1p, b1p, w2c = K.pack_mlp_weights(w1, b1, w2, lw, lb, torch.float32)
+        x = torch.randn(5, c, generator=g)
+        xin = F.layer_norm(x, (c,)) * lw + lb if with_ln else x
+        xn = F.layer_norm(x, (c,)) if with_ln else x
+        assert torch.allclose(xn @ w1p.t() + b1p, xin @ w1.t() + b1, atol=1e-4)
+        assert w2c.shape == (hid // 32, c, 32)
+        perm = torch.tensor(K._KSLOT_PERM)
+        h = torch.randn(5, hid, generator=g)
+        hp = h.view(5, hid // 32, 32)[:, :, perm]                        # the kernel holds a chunk's hidden units in k-slot order
+        assert torch.allclose(torch.einsum("mkj,kcj->mc", hp, w2c), h @ w2.t(), atol=1e-4)
+    assert K.ffn_fused_supported(256, 2048, torch.float16) and K.ffn_fused_supported(384, 2048, torch.bfloat16)
+    assert not K.ffn_fused_supported(256, 2048, torch.float32) and not K.ffn_fused_supported(192, 768, torch.float16)
+
+
 def test_postprocess_matches_golden_on_reference_outputs():
     g = load_golden("small_640")
     post = lwdetr_amd.models.PostProcess(300)

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 WG = 100
 
 
-def lib_path(sched):          # sched: LWDETR_BIG_PIPE value (0 = round-1 loop, 1 = software pipeline)
+def lib_path(sched):
     return os.path.join(ROOT, "tools", "_timing", f"libbig_t{sched}.so")
 
 
@@ -22,7 +22,7 @@ def build():
     os.makedirs(out, exist_ok=True)
     for sched in (1,):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "lw-detr_amd", "csrc"), "-j8", f"OBJDIR={out}/objbig_t{sched}",
-                               f"OUT={lib_path(sched)}", f"TUNE=-DLWDETR_BIG_TIMING={WG} -DLWDETR_BIG_PIPE={sched}"])
+                               f"OUT={lib_path(sched)}", f"TUNE=-DLWDETR_BIG_TIMING={WG}"])
 
 
 def main():
