@@ -531,15 +531,19 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
 //   chained QKV: every wave normalises the whole tile again and computes its share of the 36 feature tiles from registers.
 // No weight goes through LDS, no DMA ring, 6 barriers in all. Same packed weights and the same arithmetic per element as
 // the large kernel, except for the order in which the 24 partial sums of fc2 are added (f32).
-template <typename T, bool QKV>
+// TT = 16-token tiles per workgroup. 2 (32 tokens) from a few images up; 1 for one or two images: twice the workgroups (100
+// for one 640 x 640 image on 256 CUs) and, with half the accumulators, room to keep the fc2 fragments of a chunk and the
+// fc1 fragments of the wave's NEXT chunk in flight while the current one multiplies - the kernel is a chain of L2 round
+// trips for weights (two per hidden chunk, one per QKV feature tile), and at this size nothing else matters.
+template <typename T, bool QKV, int TT>
 __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
-    constexpr int C = 192, TT = 2, KC = C / 32, NT = C / 16, HID = 4 * C, X1_LD = C + 8;
+    constexpr int C = 192, KC = C / 32, NT = C / 16, HID = 4 * C, X1_LD = C + 8;
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     static_assert(sizeof(T) == 2, "");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* x1s = (T*)smem_raw;                                        // [32][X1_LD]: x1, then the block's output rows
-    float* part = (float*)(x1s + 32 * X1_LD);                     // [8 waves][6 tiles][2][64 lanes][4]
+    T* x1s = (T*)smem_raw;                                        // [16 TT][X1_LD]: x1, then the block's output rows
+    float* part = (float*)(x1s + 16 * TT * X1_LD);                // [8 waves][6 tiles][TT][64 lanes][4]
     float* b1s = part + NW * 6 * TT * 256;
     float* bps = b1s + HID; float* bqs = bps + 2 * C; float* b2s = bqs + 3 * C;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -629,36 +633,66 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc2[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (TT == 1) {
+        // fc1 fragments of the wave's next chunk are requested as soon as the current ones have been multiplied, the fc2
+        // fragments of a chunk before its fc1 MFMAs: one L2 round trip per chunk is exposed instead of two
+        V8 f1[2 * KC];
+#pragma unroll
+        for (int i = 0; i < 2 * KC; ++i) f1[i] = *(const V8*)(W1 + (long)(wave * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
 #pragma unroll 1
-    for (int hc = wave; hc < HID / 32; hc += NW) {
-        V8 fr[2 * KC];
+        for (int hc = wave; hc < HID / 32; hc += NW) {
+            V8 f2[NT];
 #pragma unroll
-        for (int i = 0; i < 2 * KC; ++i)        // fc1 fragment i = (kc = i / 2, h = i % 2)
-            fr[i] = *(const V8*)(W1 + (long)(hc * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
-        const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
-        f32x4 acc1[2][TT];
+            for (int n = 0; n < NT; ++n) f2[n] = *(const V8*)(W2 + (long)hc * 32 * C + (n * 16 + l15) * 32 + g * 8);
+            const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
+            f32x4 acc1[2] = {bia0, bia1};
 #pragma unroll
-        for (int t = 0; t < TT; ++t) { acc1[0][t] = bia0; acc1[1][t] = bia1; }
+            for (int i = 0; i < 2 * KC; ++i) acc1[i & 1] = Mma<T>::k32(f1[i], xf[0][i >> 1], acc1[i & 1]);
+            const int hn = hc + NW < HID / 32 ? hc + NW : hc;            // last chunk: a harmless reload
 #pragma unroll
-        for (int i = 0; i < 2 * KC; ++i)
-#pragma unroll
-            for (int t = 0; t < TT; ++t) acc1[i & 1][t] = Mma<T>::k32(fr[i], xf[t][i >> 1], acc1[i & 1][t]);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)            // fc2 fragments of the chunk: in flight while GELU runs
-            fr[n] = *(const V8*)(W2 + (long)hc * 32 * C + (n * 16 + l15) * 32 + g * 8);
-        V8 hf[TT];
-#pragma unroll
-        for (int t = 0; t < TT; ++t)
+            for (int i = 0; i < 2 * KC; ++i) f1[i] = *(const V8*)(W1 + (long)(hn * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
+            V8 hf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hf[t][e] = from_f32<T>(gelu_for<T>(acc1[0][t][e]));
-                hf[t][4 + e] = from_f32<T>(gelu_for<T>(acc1[1][t][e]));
+                hf[e] = from_f32<T>(gelu_for<T>(acc1[0][e]));
+                hf[4 + e] = from_f32<T>(gelu_for<T>(acc1[1][e]));
             }
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int t = 0; t < TT; ++t) acc2[n][t] = Mma<T>::k32(fr[n], hf[t], acc2[n][t]);
-    }
+            for (int n = 0; n < NT; ++n) acc2[n][0] = Mma<T>::k32(f2[n], hf, acc2[n][0]);
+        }
+    } else {
+#pragma unroll 1
+        for (int hc = wave; hc < HID / 32; hc += NW) {
+            V8 fr[2 * KC];
+    #pragma unroll
+            for (int i = 0; i < 2 * KC; ++i)        // fc1 fragment i = (kc = i / 2, h = i % 2)
+                fr[i] = *(const V8*)(W1 + (long)(hc * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
+            const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
+            f32x4 acc1[2][TT];
+    #pragma unroll
+            for (int t = 0; t < TT; ++t) { acc1[0][t] = bia0; acc1[1][t] = bia1; }
+    #pragma unroll
+            for (int i = 0; i < 2 * KC; ++i)
+    #pragma unroll
+                for (int t = 0; t < TT; ++t) acc1[i & 1][t] = Mma<T>::k32(fr[i], xf[t][i >> 1], acc1[i & 1][t]);
+    #pragma unroll
+            for (int n = 0; n < NT; ++n)            // fc2 fragments of the chunk: in flight while GELU runs
+                fr[n] = *(const V8*)(W2 + (long)hc * 32 * C + (n * 16 + l15) * 32 + g * 8);
+            V8 hf[TT];
+    #pragma unroll
+            for (int t = 0; t < TT; ++t)
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hf[t][e] = from_f32<T>(gelu_for<T>(acc1[0][t][e]));
+                    hf[t][4 + e] = from_f32<T>(gelu_for<T>(acc1[1][t][e]));
+                }
+    #pragma unroll
+            for (int n = 0; n < NT; ++n)
+    #pragma unroll
+                for (int t = 0; t < TT; ++t) acc2[n][t] = Mma<T>::k32(fr[n], hf[t], acc2[n][t]);
+        }
+    
+}
 
     // ---- reduction over the 8 waves + epilogue, 6 channel tiles per round; wave w < 6 finishes channel tile 6 r + w
     T* __restrict__ O2 = (T*)p.out2;
@@ -724,11 +758,20 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
     constexpr int NTQ = 3 * C / 16;
     const T* __restrict__ WQ = (const T*)p.wqkv;
     T* __restrict__ Qo = (T*)p.q; T* __restrict__ Ko = (T*)p.k; T* __restrict__ Vo = (T*)p.vt;
-#pragma unroll 1
-    for (int nt = wave; nt < NTQ; nt += NW) {
-        V8 wq[KC];
+    // feature tiles wave, wave + 8, ...: the weights of the next tile are requested before the current one is multiplied
+    constexpr int NIT = (NTQ + NW - 1) / NW;
+    V8 wq[2][KC];
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) wq[kc] = *(const V8*)(WQ + (long)(nt * 16 + l15) * C + kc * 32 + g * 8);
+    for (int kc = 0; kc < KC; ++kc) wq[0][kc] = *(const V8*)(WQ + (long)(wave * 16 + l15) * C + kc * 32 + g * 8);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int nt = wave + it * NW;
+        if (it + 1 < NIT) {
+            const int ntn = nt + NW < NTQ ? nt + NW : NTQ - 1;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) wq[(it + 1) & 1][kc] = *(const V8*)(WQ + (long)(ntn * 16 + l15) * C + kc * 32 + g * 8);
+        }
+        if (nt >= NTQ) break;                                          // wave-uniform
         const int sg = nt / (C / 16), nl0 = (nt - sg * (C / 16)) * 16;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -736,7 +779,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
                 const int nl = nl0 + g * 4, hh = nl / p.hd, dd = nl - hh * p.hd;
                 f32x4 acc = *(const f32x4*)(bqs + sg * C + nl);
 #pragma unroll
-                for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(wq[kc], xq[t][kc], acc);
+                for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(wq[it & 1][kc], xq[t][kc], acc);
                 const int mq = (int)m0 + t * 16 + l15, bq_ = mq / p.Tp;
                 if (mq < p.M) {
                     T* dst = (sg == 0 ? Qo : Ko) + ((long)bq_ * p.heads * p.Tp + (mq - bq_ * p.Tp)) * p.hd + (long)hh * p.Tp * p.hd + dd;
@@ -747,7 +790,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
                 const float bb = bqs[2 * C + nl];
                 f32x4 acc = {bb, bb, bb, bb};
 #pragma unroll
-                for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(xq[t][kc], wq[kc], acc);
+                for (int kc = 0; kc < KC; ++kc) acc = Mma<T>::k32(xq[t][kc], wq[it & 1][kc], acc);
                 const int mv = (int)m0 + t * 16 + g * 4, bv_ = mv / p.Tp;
                 if (mv < p.M)
                     *(V4*)(Vo + (long)bv_ * p.heads * p.hd * p.Tp + (mv - bv_ * p.Tp) + ((long)hh * p.hd + dd) * p.Tp) = cvt4<T>(acc);
@@ -755,21 +798,27 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
         }
     }
 }
-
-template <typename T, bool QKV>
-int launch_mlp_small(const MlpParams& p, hipStream_t st) {
+constexpr long MLP_SMALL_TT1_MAX_ROWS = 3200;      // one or two 640 x 640 images: 16-token workgroups (see mlp_small_kernel)
+template <typename T, bool QKV, int TT>
+int launch_mlp_small_tt(const MlpParams& p, hipStream_t st) {
     constexpr int C = 192;
-    constexpr size_t lds = 32 * (C + 8) * sizeof(T) + (size_t)NW * 6 * 2 * 256 * sizeof(float) + 11 * C * sizeof(float);
+    constexpr size_t lds = 16 * TT * (C + 8) * sizeof(T) + (size_t)NW * 6 * TT * 256 * sizeof(float) + 11 * C * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)mlp_small_kernel<T, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)mlp_small_kernel<T, QKV, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
         attr_done = true;
     }
-    const long blocks = (p.M + 31) / 32;
+    const long blocks = (p.M + 16 * TT - 1) / (16 * TT);
     ProfScope ps(KID_MLP, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C, (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T), st);
-    hipLaunchKernelGGL((mlp_small_kernel<T, QKV>), dim3((unsigned)blocks), dim3(NTHR), lds, st, p);
+    hipLaunchKernelGGL((mlp_small_kernel<T, QKV, TT>), dim3((unsigned)blocks), dim3(NTHR), lds, st, p);
     return lwdetr_check_launch();
+}
+template <typename T, bool QKV>
+int launch_mlp_small(const MlpParams& p, hipStream_t st) {
+    static const char* env = getenv("LWDETR_MLP_SMALL_TT");          // tuning: 1 / 2 = tokens tiles per workgroup
+    const int tt = env ? atoi(env) : (p.M <= MLP_SMALL_TT1_MAX_ROWS ? 1 : 2);
+    return tt == 1 ? launch_mlp_small_tt<T, QKV, 1>(p, st) : launch_mlp_small_tt<T, QKV, 2>(p, st);
 }
 
 template <typename T, int C, int TT, bool PROJ, bool QKV>

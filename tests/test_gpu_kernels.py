@@ -368,11 +368,12 @@ def test_ffn_fused(dtype, c, hid, m):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("c,m", [(192, 1000), (192, 64), (384, 333), (192, 51200), (192, 20000), (192, 64000), (384, 25600)])
+@pytest.mark.parametrize("c,m", [(192, 1000), (192, 64), (192, 6400), (384, 333), (192, 51200), (192, 20000), (192, 64000), (384, 25600)])
 def test_mlp_fused(dtype, c, m):
     """LN -> fc1 -> GELU -> fc2 -> LayerScale -> residual in one launch vs the unfused torch fp32 formulation.
     The large M are the BASELINE full sizes (51200 = 32 images x 1600 tokens: 6-7 tiles per workgroup, the LDS-resident
-    residual path), a ragged tile count (20000) and more than 7 tiles per CU (64000: extra rounds)."""
+    residual path), a ragged tile count (20000) and more than 7 tiles per CU (64000: extra rounds); 64 / 1000 rows run the
+    few-token kernel with 16-token workgroups, 6400 rows (4 images) with 32-token ones."""
     from lwdetr_amd import kernels as K
     if not K.mlp_fused_supported(c, dtype):
         pytest.skip("not instantiated for this shape / dtype")
@@ -405,8 +406,7 @@ def test_mlp_fused(dtype, c, m):
     assert _relerr(xx, ref2) < tol, _relerr(xx, ref2)
     # ... and with the next block's LayerNorm + QKV chained behind it (Q / K head layout, V transposed)
     heads, hd = 12, c // 12
-    tp = 100 if m % 100 == 0 else 4 * (m // 4 // 1) if False else None
-    tp = {1000: 100, 64: 64, 333: None, 51200: 1600, 20000: 400, 64000: 1600, 25600: 1600}[m]
+    tp = {1000: 100, 64: 64, 6400: 1600, 333: None, 51200: 1600, 20000: 400, 64000: 1600, 25600: 1600}[m]
     if tp is not None:
         nb = m // tp
         wqkv = _rand(3 * c, c, scale=c ** -0.5, seed=13)
