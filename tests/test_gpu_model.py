@@ -157,7 +157,7 @@ def test_full_size_batch_is_consistent_with_the_golden_validated_small_batch_pat
     carried by size-independent properties: (a) bit-identical repeat, (b) images are independent - the first 4 images of
     the batch give the same tensors as a batch of 4 run through the launch plan the golden tests validate (separate ViT
     launches, 1 tile per workgroup), up to fp16 round-off of the differently-fused arithmetic, with the two-stage selection
-    teacher-forced, (c) the fused and the unfused ViT plans agree on the whole batch."""
+    teacher-forced, (c) the fused and the unfused ViT plans agree on the whole batch, (d) so do the two decoder-FFN plans."""
     from lwdetr_amd.synth import synth_images, synth_state_dict
     cfg = lwdetr_amd.get_args("small")
     model, _crit, _post = lwdetr_amd.build_model(cfg)
@@ -182,6 +182,14 @@ def test_full_size_batch_is_consistent_with_the_golden_validated_small_batch_pat
     sel = model(x, _collect=col)
     overlap = np.mean([len(set(a) & set(b)) / len(b) for a, b in zip(col["topk_idx"].cpu().numpy(), topk.cpu().numpy())])
     assert overlap > 0.9, overlap
+    # (d) the decoder FFN as split-hidden block kernel + finishing LayerNorm chain (default) vs three launches per layer: the
+    # same 16-bit roundings, f32 sums in another order
+    monkeypatch.setenv("LWDETR_MLP_FUSED", "1")
+    monkeypatch.setenv("LWDETR_FFN_FUSED", "0")
+    model.invalidate_cache()
+    ffn3 = model(x, _forced_topk=topk)
+    assert (ffn3["pred_logits"].float() - forced["pred_logits"].float()).abs().max().item() < 0.05
+    assert (ffn3["pred_boxes"].float() - forced["pred_boxes"].float()).abs().max().item() < 0.01
 
 
 def test_forward_export_matches_dict_forward():
