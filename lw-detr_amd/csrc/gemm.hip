@@ -114,8 +114,8 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                 constexpr int ITS = 64 / RSTEP;
                 const bool fast = 64 % RSTEP == 0 && mbase + 64 <= d.M && !sg.rowmask && !out2 && (n_end - n0) % 8 == 0 &&
                                   (sg.mode == LWDETR_OUT_LINEAR || sg.mode == LWDETR_OUT_HEADS) && sg.ldo % 8 == 0 &&
-                                  ((size_t)out & 15) == 0 && (sg.mode == LWDETR_OUT_LINEAR || sg.p1 % 8 == 0) &&
-                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0 && sg.n_begin % 8 == 0));
+                                  ((size_t)out & 15) == 0 && (sg.mode == LWDETR_OUT_LINEAR || sg.p1 % 8 == 0) && sg.n_begin % 8 == 0 &&
+                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0));
                 if (fast) {
                     constexpr int G = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
                     auto finish_all = [&](auto act_tag) {
