@@ -24,6 +24,7 @@
  *   lwdetr_attention           models/backbone/vit.py:130-137 (window and global softmax(QK^T)V) and
  *                              models/attention.py:563-606 (decoder self-attention)
  *   lwdetr_mlp_fused           models/backbone/vit.py:217-218 (+ timm.models.layers.Mlp: fc1 -> GELU -> fc2)
+ *   lwdetr_vit_block           models/backbone/vit.py:138, :199-218, :123-130 (projection + MLP + next block's norm1 / QKV)
  *   lwdetr_ffn_partial/_finish models/transformer.py:507-512, :397-400 (decoder FFN + norm3 + decoder.norm)
  *   lwdetr_layernorm           nn.LayerNorm call sites (vit.py:199,:217; transformer.py:231,:499,:511,:516,:398) and
  *                              the channel LayerNorm of models/backbone/projector.py:21-47
@@ -183,6 +184,21 @@ int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_f
                      float eps, float eps_next, const void* att, long ldatt, const void* wp, const float* bp,
                      const float* gamma1, const void* wqkv_next, const float* bqkv_next, void* q_out, void* k_out,
                      void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream);
+
+/* ---- fused ViT block tail (round 3; 16-bit dtypes, C in {192, 384}, M % 4 == 0) --------------------------------------
+ * Replaces, per ViT block, models/backbone/vit.py:138 + :206-216 (attention output projection, gamma_1, residual),
+ * :217-218 (norm2 -> timm Mlp -> gamma_2 -> residual) and, with has_qkv, :199 + :123-130 of the NEXT block (norm1, QKV with
+ * q_bias / v_bias; Q pre-scaled by qscale, Q / K as (B, heads, Tp, hd), V^T as (B, heads, hd, Tp) like lwdetr_gemm's HEADS /
+ * HEADS_T epilogues). x (M, C) is updated in place, att (M, C) is the attention output; out2 (optional) receives a copy
+ * of the new rows (feature taps), stats_out (optional, (M, 2) f32) mean and 1/sqrt(var + eps_next) of the new rows.
+ * wstream / vec: lwdetr_amd.kernels.pack_vit_block (all weights of the block as one stream of 1 KB MFMA fragments in
+ * consumption order; f32 vectors b1' | bp | g1 | 1/g1 | b2 | 1/g2 | g2 | bqkv'); sizes from the two helpers below.
+ * hd must be a power of two; gamma_1 / gamma_2 must be non-zero (the kernel divides by them in f32). */
+long lwdetr_vit_block_stream_bytes(int C, int has_qkv);
+long lwdetr_vit_block_vec_floats(int C);
+int lwdetr_vit_block(void* x, long ldx, const void* att, long ldatt, const void* wstream, const float* vec, void* out2,
+                     long ld2, float* stats_out, long M, int C, float eps, float eps_next, int has_qkv, void* q_out,
+                     void* k_out, void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream);
 
 /* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
  * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */

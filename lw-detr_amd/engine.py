@@ -206,7 +206,20 @@ class ForwardPlan:
             if i in self.taps:
                 j = self.taps.index(i)
                 tap_out = self.taps_cat[:, j * C:]
-            if fused:
+            if fused and K.vit_block_supported(C, self.T, hd, rows) and self._vit_block_ok(blk):
+                # round-3 kernel (BASELINE batch sizes): projection + MLP + the next block's norm1 / QKV, one launch
+                sd_ = pw.sd
+                qkv_src, nxt = None, {}
+                if i + 1 < self.depth:
+                    nb = f"{pre}.blocks.{i + 1}"
+                    qkv_src = tuple(sd_[nb + k_] for k_ in (".attn.qkv.weight", ".attn.q_bias", ".attn.v_bias", ".norm1.weight", ".norm1.bias"))
+                    nxt = dict(q=q, k=k, vt=vt, qscale=qscale, heads=heads, hd=hd, Tp=Tp)
+                stream_w, vec = pw.custom_multi(blk + ".vitblock.packed", lambda blk=blk, qkv_src=qkv_src: K.pack_vit_block(
+                    sd_[blk + ".attn.proj.weight"], sd_[blk + ".attn.proj.bias"], sd_[blk + ".gamma_1"],
+                    sd_[blk + ".mlp.fc1.weight"], sd_[blk + ".mlp.fc1.bias"], sd_[blk + ".mlp.fc2.weight"], sd_[blk + ".mlp.fc2.bias"],
+                    sd_[blk + ".gamma_2"], sd_[blk + ".norm2.weight"], sd_[blk + ".norm2.bias"], self.T, qkv=qkv_src))
+                ops.append(K.VitBlockOp(self.x, att, stream_w, vec, rows, C, 1e-6, out2=tap_out, ld2=ntap * C, eps_next=1e-6, **nxt))
+            elif fused:
                 # one launch: x += gamma1 * proj(att); x += gamma2 * fc2(GELU(fc1(LN(x))))  (vit.py:206-218)
                 w1f, b1f, w2c = pw.custom_multi(blk + ".mlp.packed", lambda blk=blk: K.pack_mlp_weights(
                     pw.sd[blk + ".mlp.fc1.weight"], pw.sd[blk + ".mlp.fc1.bias"], pw.sd[blk + ".mlp.fc2.weight"],
@@ -229,6 +242,11 @@ class ForwardPlan:
                 ops.append(GemmOp(hid, pw.w(blk + ".mlp.fc2.weight"), rows, C, 4 * C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".mlp.fc2.bias"), gamma=pw.f(blk + ".gamma_2"), res=self.x,
                         ldres=C, out2=tap_out, ld2=ntap * C)], keep=(tap_out,)))
+
+    def _vit_block_ok(self, blk):
+        """lwdetr_vit_block divides by the LayerScale vectors: blocks with (near-)zero entries stay on lwdetr_mlp_fused."""
+        sd_ = self.pw.sd
+        return min(sd_[blk + ".gamma_1"].detach().abs().min().item(), sd_[blk + ".gamma_2"].detach().abs().min().item()) >= K._VB_MIN_GAMMA
 
     # ------------------------------------------------------------------------------------------ projector
     def _convx_1x1(self, prefix, A, lda, M, cin, out_seg_fn, a_ptr_off=0):

@@ -250,6 +250,106 @@ class MlpFusedOp:
             _nat.check(rc, "mlp_fused")
 
 
+# ---------------------------------------------------------------------------------------- fused ViT block (round 3)
+VIT_BLOCK_MIN_ROWS = 12800      # below ~8 images of 640x640 the few-token kernels of lwdetr_mlp_fused win (bs=1 latency path)
+_VB_MIN_GAMMA = 1e-12           # the kernel divides by gamma_1 / gamma_2 (f32): refuse zero / denormal LayerScale entries
+
+
+def vit_block_supported(C_, dtype, hd=None, rows=None) -> bool:
+    """Shapes / dtypes lwdetr_vit_block is instantiated for; with ``rows`` the launch-plan choice (LWDETR_VIT_BLOCK=0/1 forces)."""
+    ok = C_ in (192, 384) and dtype in (torch.float16, torch.bfloat16) and (hd is None or (hd >= 4 and hd & (hd - 1) == 0))
+    if not ok or rows is None:
+        return ok
+    force = os.environ.get("LWDETR_VIT_BLOCK")
+    if force in ("0", "1"):
+        return force == "1"
+    return rows >= VIT_BLOCK_MIN_ROWS and rows % 4 == 0
+
+
+def vb_kslot_channels(c):
+    """Channel held by k-slot position p = 16 t + 8 h + s of an accumulator tile handed on as a B operand (vitblock.hip):
+    t = 2 n + beta, s = 4 b' + e  <->  channel 32 n + 16 beta + 8 b' + 4 h + e."""
+    idx = []
+    for t in range(c // 16):
+        n, be = divmod(t, 2)
+        for h in range(2):
+            for s_ in range(8):
+                bp, e = divmod(s_, 4)
+                idx.append(32 * n + 16 * be + 8 * bp + 4 * h + e)
+    return torch.tensor(idx)
+
+
+def _vb_frags(w32):
+    """(32, K) rows in k-slot order -> (K/16, 2, 32, 8): fragment t, lane half h, row i, element s (= lane-linear 1 KB pieces)."""
+    return w32.reshape(32, -1, 2, 8).permute(1, 2, 0, 3).contiguous()
+
+
+def pack_vit_block(wp, bp, g1, w1, b1, w2, b2, g2, ln2_w, ln2_b, dtype, qkv=None):
+    """Host-side packing for lwdetr_vit_block (f32 master tensors in): returns (stream of ``dtype``, vec f32).
+
+    stream = pieces of 32 rows x C (or C x 32) in consumption order, every piece KS = C/16 fragments of 1 KB in MFMA lane
+    order: Wp tiles 0..C/32-1 (natural k order: the attention rows come straight from memory); W1c(0), W1c(1), then
+    (W2c(k-1), W1c(k+1)) for k = 1..NCH-2, W2c(NCH-2), W2c(NCH-1) (W1 = fc1 * ln2_w with its columns in k-slot order,
+    W2c(k) = fc2[:, 32k..32k+31] as fragments (k-step, output tile) with the hidden units in accumulator order); optionally
+    the next block's Wqkv' tiles (``qkv`` = (wqkv, q_bias, v_bias, ln1_w, ln1_b), LayerNorm affine folded, k-slot order).
+    vec = b1' | bp | g1 | 1/g1 | b2 | 1/g2 | g2 | bqkv' zero-padded to a multiple of 4 KB."""
+    f = lambda t: t.detach().float().cpu()
+    wp, bp, g1, w1, b1, w2, b2, g2, ln2_w, ln2_b = map(f, (wp, bp, g1, w1, b1, w2, b2, g2, ln2_w, ln2_b))
+    c = wp.shape[0]
+    hid = w1.shape[0]
+    assert c in (192, 384) and hid == 4 * c and w2.shape == (c, hid)
+    if min(g1.abs().min().item(), g2.abs().min().item()) < _VB_MIN_GAMMA:
+        raise ValueError("lwdetr_vit_block needs non-zero LayerScale (gamma_1 / gamma_2)")
+    nti, nch = c // 32, hid // 32
+    perm = vb_kslot_channels(c)
+    w1f = (w1 * ln2_w[None, :])[:, perm]
+    b1f = b1 + w1 @ ln2_b
+    pieces = [_vb_frags(wp[32 * n:32 * n + 32]) for n in range(nti)]
+    w1c = lambda k: _vb_frags(w1f[32 * k:32 * k + 32])
+
+    def w2c(k):
+        # A2[n, i, kap, h, s] = w2[32 n + i, 32 k + 16 kap + 8 (s // 4) + 4 h + s % 4]; fragments ordered (kap, n), each (h, i, s)
+        blk = w2[:, 32 * k:32 * k + 32].reshape(nti, 32, 2, 2, 2, 4)           # n, i, kap, b', h, e
+        return blk.permute(2, 0, 4, 1, 3, 5).reshape(2 * nti, 2, 32, 8).contiguous()   # (kap, n), h, i, (b', e)
+
+    pieces += [w1c(0), w1c(1)]
+    for k in range(1, nch - 1):
+        pieces += [w2c(k - 1), w1c(k + 1)]
+    pieces += [w2c(nch - 2), w2c(nch - 1)]
+    bq = torch.zeros(3 * c)
+    if qkv is not None:
+        wqkv, q_bias, v_bias, ln1_w, ln1_b = map(f, qkv)
+        bq = torch.cat([q_bias, torch.zeros_like(q_bias), v_bias]) + wqkv @ ln1_b
+        wq = (wqkv * ln1_w[None, :])[:, perm]
+        pieces += [_vb_frags(wq[32 * i:32 * i + 32]) for i in range(3 * nti)]
+    stream = torch.cat([p_.reshape(-1) for p_ in pieces]).to(dtype).contiguous()
+    vec = torch.cat([b1f, bp, g1, 1.0 / g1, b2, 1.0 / g2, g2, bq])
+    nvec = (13 * c * 4 + 4095) // 4096 * 4096 // 4
+    vec = torch.cat([vec, torch.zeros(nvec - vec.numel())]).contiguous()
+    return stream, vec
+
+
+class VitBlockOp:
+    """x <- block tail (attention projection + MLP, + norm1 / QKV of the next block) in one launch (lwdetr_vit_block)."""
+
+    def __init__(self, x, att, stream, vec, M, C_, eps, *, ldx=None, ldatt=None, out2=None, ld2=0, stats_out=None, eps_next=1e-6,
+                 q=None, k=None, vt=None, qscale=1.0, heads=0, hd=0, Tp=0):
+        assert stream.dtype == x.dtype == att.dtype and vec.dtype == torch.float32 and stream.is_contiguous() and vec.is_contiguous()
+        has_qkv = q is not None
+        nti = C_ // 32
+        assert stream.numel() == (nti + 8 * nti + (3 * nti if has_qkv else 0)) * (C_ // 16) * 512, "stream / qkv mismatch"
+        self.args = (_ptr(x), ldx if ldx is not None else C_, _ptr(att), ldatt if ldatt is not None else C_, _ptr(stream),
+                     _ptr(vec), _ptr(out2), ld2, _ptr(stats_out), M, C_, float(eps), float(eps_next), 1 if has_qkv else 0,
+                     _ptr(q), _ptr(k), _ptr(vt), float(qscale), heads, hd, Tp, _nat.dtype_code(x.dtype))
+        self._keep = (x, att, stream, vec, out2, stats_out, q, k, vt)
+        self._fn = _nat.lib().lwdetr_vit_block
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "vit_block")
+
+
 class RawOp:
     """Generic pre-bound launch: ``fn(*args, stream)`` of the C ABI (keeps the tensors behind the pointers alive)."""
 
