@@ -27,6 +27,24 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Phase timing for kernel tuning (tools/vitblock_timing.py builds a private copy with -DLWDETR_VB_TIMING; never in the product
+// library): s_memrealtime stamps (10 ns ticks) of every wave of two workgroups at the phase boundaries, plus the time spent in
+// the ring waits and barriers of the hidden loop.
+// Ablation builds for tuning (-DLWDETR_VB_ABLATE=bits, results are WRONG; never in the product): 1 = no GELU ticks in the hidden
+// loop, 2 = no MFMAs there, 4 = no weight DMA after the prologue, 8 = no fragment reads in the hidden loop.
+#ifndef LWDETR_VB_ABLATE
+#define LWDETR_VB_ABLATE 0
+#endif
+#ifdef LWDETR_VB_TIMING
+__device__ unsigned long long g_vb_timing[2][4][16];
+#define VB_TS(i) do { if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) g_vb_timing[blockIdx.x != 0][wave][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int lwdetr_debug_vb_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vb_timing), sizeof(g_vb_timing)) == hipSuccess ? 0 : 1;
+}
+#else
+#define VB_TS(i) do {} while (0)
+#endif
+
 namespace {
 
 template <typename T> struct Mma32;
@@ -37,6 +55,14 @@ template <> struct Mma32<bf16> {
     static __device__ __forceinline__ f32x16 k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
+// compile-time loop: f(integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{}) (the hidden loop's slots must be
+// constants for `if constexpr`; a 48-iteration `#pragma unroll` body with run-time-looking branches exceeds hipcc's threshold)
+template <typename F, int... I> __device__ __forceinline__ void vb_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void vb_static_for(F&& f) {
+    vb_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -48,6 +74,15 @@ template <> struct Pk<bf16> { typedef bf16x2 v2; };
 template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b) {
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, typename Pk<T>::v2));
+}
+// Accumulator registers 8 jb .. 8 jb + 7 of a tile are rows 16 jb + 4 h + {0..3} (a) and 16 jb + 8 + 4 h + {0..3} (b) of column
+// j. Exchanging a's upper half-wave with b's lower one (v_permlane32_swap) leaves every lane with 8 CONSECUTIVE rows
+// 16 jb + 8 h .. + 7: one 16-byte store instead of two 8-byte ones (the store path is issue-bound: 12 us of epilogue measured
+// with 8-byte pieces). a / b: the lane's own two packed pairs each.
+__device__ __forceinline__ u32x4 vb_rows8(unsigned a0, unsigned a1, unsigned b0, unsigned b1) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    return u32x4{s0[0], s1[0], s0[1], s1[1]};
 }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -117,11 +152,11 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     const unsigned lane16 = lane * 16;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
 
-    // ---- this wave's tokens: 4-token units dealt evenly over all waves of the grid (at most 32 * NH per wave: host)
-    const long U = p.M >> 2, nwv = (long)gridDim.x * 4, wg = (long)blockIdx.x * 4 + wave;
+    // ---- this wave's tokens: 8-token units dealt evenly over all waves of the grid (at most 32 * NH per wave: host)
+    const long U = p.M >> 3, nwv = (long)gridDim.x * 4, wg = (long)blockIdx.x * 4 + wave;
     const long u0 = wg * U / nwv, u1 = (wg + 1) * U / nwv;
-    const long t0 = u0 * 4;
-    const int nvalid = (int)(u1 - u0) * 4;
+    const long t0 = u0 * 8;
+    const int nvalid = (int)(u1 - u0) * 8;
 
     // ---- weight stream: linear LDS-DMA, 1 KB per wave-instruction (inline asm: hipcc must not turn the pending pieces into
     // lgkmcnt(0) drains of the fragment reads, cf. mlp.hip). Piece i lives in ring slot i % NSLOT.
@@ -145,16 +180,32 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     int issued = 0;
     // step boundary: the step consumes pieces [a, b), everything below a is dead. `extra` = vector-memory operations this wave
     // is KNOWN to have issued after its DMA of piece b - 1 besides later pieces (a lower bound is safe, it only waits longer).
+#ifdef LWDETR_VB_TIMING
+    unsigned long long tt_wait = 0, tt_bar = 0;
+#endif
     auto boundary = [&](int a, int b, int extra) {
+#ifdef LWDETR_VB_TIMING
+        const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
+#endif
         vb_wait_le((issued - b) * DPW + extra);
+#ifdef LWDETR_VB_TIMING
+        const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef LWDETR_VB_TIMING
+        tt_wait += tb - ta; tt_bar += __builtin_amdgcn_s_memrealtime() - tb;
+#endif
         int lim = a + NSLOT; lim = lim < NP ? lim : NP;
+#if LWDETR_VB_ABLATE & 4
+        if (a >= H0) { issued = lim; return; }
+#endif
         while (issued < lim) { dma_piece(issued); ++issued; }
     };
     auto frag = [&](int piece, int f) -> V8 {
         return *(const V8*)(smem + ((unsigned)piece % NSLOT) * PIECE_B + f * 1024 + lane16);
     };
 
+    VB_TS(0);
     // ---- prologue: vectors + the first NSLOT pieces in flight, then the attention rows as B fragments
     {
         const char* vsrc = (const char*)p.vec;
@@ -182,31 +233,41 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     // start at x / gamma1 + bp (x in accumulator layout: 4 channels 32 n + 8 b + 4 h .. of token j), so x1 = gamma1 * acc and the
     // x rows are consumed before the first MFMA (no second copy of the residual stream in registers).
     {
-        V4 xv[NH][NTI][4];
+        u32x4 xv[NH][NTI][2];                   // 16-byte loads: channels 32 n + 16 jb + 8 h .. + 7 of token j
 #pragma unroll
         for (int th = 0; th < NH; ++th)
 #pragma unroll
             for (int n = 0; n < NTI; ++n)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    xv[th][n][b] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b64(
-                        r_x, (unsigned)(((32 * th + j) * p.ldx + 32 * n + 8 * b + 4 * h) * 2), 0, 0));
+                for (int jb = 0; jb < 2; ++jb)
+                    xv[th][n][jb] = __builtin_amdgcn_raw_buffer_load_b128(
+                        r_x, (unsigned)(((32 * th + j) * p.ldx + 32 * n + 16 * jb + 8 * h) * 2), 0, 0);
         // loads issued after the DMA of the initial pieces: the attention and x rows
-        boundary(0, 2, NH * KS + NH * NTI * 4);
+        boundary(0, 2, NH * KS + NH * NTI * 2);
+        VB_TS(1);
 #pragma unroll
         for (int n = 0; n < NTI; ++n) {
             f32x16 na[NH];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int c0 = 32 * n + 8 * b + 4 * h;
-                const f32x4 bb = *(const f32x4*)(bps + c0), rg = *(const f32x4*)(rg1s + c0);
+            for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                 for (int th = 0; th < NH; ++th) {
-                    const f32x4 xo = up4<T>(xv[th][n][b]);
+                    // the half-wave exchange of vb_rows8 is its own inverse: back to this lane's accumulator rows
+                    const u32x4 own = vb_rows8(xv[th][n][jb][0], xv[th][n][jb][1], xv[th][n][jb][2], xv[th][n][jb][3]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) na[th][4 * b + e] = fmaf(xo[e], rg[e], bb[e]);
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int b = 2 * jb + bb, c0 = 32 * n + 8 * b + 4 * h;
+                        const f32x4 bbv = *(const f32x4*)(bps + c0), rg = *(const f32x4*)(rg1s + c0);
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            // (a scalar copy first: __builtin_bit_cast of an ext-vector ELEMENT reads element 0 whatever the index - hipcc 7.2)
+                            const unsigned ow_ = own[2 * bb + d];
+                            const typename Pk<T>::v2 v2 = __builtin_bit_cast(typename Pk<T>::v2, ow_);
+                            na[th][4 * b + 2 * d] = fmaf(to_f32<T>(v2[0]), rg[2 * d], bbv[2 * d]);
+                            na[th][4 * b + 2 * d + 1] = fmaf(to_f32<T>(v2[1]), rg[2 * d + 1], bbv[2 * d + 1]);
+                        }
+                    }
                 }
-            }
 #pragma unroll
             for (int th = 0; th < NH; ++th) {
                 asm volatile("" : "+a"(na[th]));      // complete tile, in the accumulator file (see the LayerNorm section)
@@ -215,9 +276,10 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    VB_TS(2);
 #pragma unroll
     for (int s = 0; s < NTI / 2; ++s) {
-        if (s > 0) boundary(2 * s, 2 * s + 2, 2 * s + 1 < NSLOT ? NH * KS + NH * NTI * 4 : 0);
+        if (s > 0) boundary(2 * s, 2 * s + 2, 2 * s + 1 < NSLOT ? NH * KS + NH * NTI * 2 : 0);
         {   // 2 KS fragments through the read-ahead ring, one read per fragment retired (hipcc would hoist all 2 KS reads)
             V8 fr[RD];
 #pragma unroll
@@ -233,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
             }
         }
     }
+    VB_TS(3);
     // ---- x1 = gamma1 * acc rounded to the storage type; LayerNorm (affine folded into W1 / b1) -> B fragments; the fc2
     // accumulators start at x1 / gamma2 + b2 (the epilogue is out = gamma2 * acc). x1 is held as packed 16-bit pairs between
     // the three passes (sum, variance, normalise): 48 registers per token half instead of 96 f32 values.
@@ -298,6 +361,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         }
     }
 
+    VB_TS(4);
     // ---- hidden loop, software pipelined. Pieces after the projection: W1c(0), W1c(1), then (W2c(k-1), W1c(k+1)) for k = 1 ..
     // NCH-2, then W2c(NCH-2), W2c(NCH-1). Iteration k: GELU(k) on the VALU, fc2(k-1) and fc1(k+1) on the matrix pipe.
     f32x16 acc1[2][NH];
@@ -317,47 +381,72 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
         constexpr bool DO2 = decltype(fc2_tag)::value, DO1 = decltype(fc1_tag)::value;
         constexpr int NF2 = DO2 ? 2 * NTI : 0, NF1 = DO1 ? KS : 0, NF = NF2 + NF1, S = NF * NH;
-        constexpr int TK = 24 * NH;                           // GELU ticks: 8 NH value pairs x 3 stages
+        // GELU of chunk k in "layer ticks": a tick applies ONE instruction of the GELU chain to the 8 values of a group (one
+        // (token half, k-step) B operand of fc2), so consecutive instructions of a chain sit a whole MFMA slot apart - with one
+        // wave per SIMD nothing else hides VALU / transcendental result latency (3-stage ticks on 2 values measured 1.8 us per
+        // iteration, most of it dependency stalls). 10 layers x 2 NH groups of ticks over the iteration's MFMA slots.
+        constexpr int NG = 2 * NH, TK = 10 * NG;
         auto fragi = [&](int i) -> V8 { return i < NF2 ? frag(p2, i) : frag(p1, i - NF2); };
         f32x16 bias = {};
         V8 fr[RD];
 #pragma unroll
         for (int i = 0; i < RD; ++i) if (i < NF) fr[i] = fragi(i);
-        float gx2[2], gp[2];
+        float ga[8], gb[8];
+#define VB_PIN8(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
+        auto tick = [&](auto ti_tag) {
+            constexpr int ti = decltype(ti_tag)::value, grp = ti / 10, L = ti % 10, th = grp >> 1, r0 = 8 * (grp & 1);
 #pragma unroll
-        for (int m = 0; m < S; ++m) {
-            // GELU ticks of this slot
-#pragma unroll
-            for (int ti = m * TK / S; ti < (m + 1) * TK / S; ++ti) {
-                const int pair = ti / 3, st = ti % 3, th = pair / 8, r0 = (pair % 8) * 2;
-                if (st == 0) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) gelu_s0(acc1[CUR][th][r0 + u], gx2[u], gp[u]);
-                    asm volatile("" : "+v"(gx2[0]), "+v"(gx2[1]), "+v"(gp[0]), "+v"(gp[1]));
-                } else if (st == 1) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) gp[u] = gelu_s1(acc1[CUR][th][r0 + u], gx2[u], gp[u]);
-                    asm volatile("" : "+v"(gp[0]), "+v"(gp[1]));
-                } else {
-                    const int bq = r0 >> 2, e0 = r0 & 3;             // register 4 bq + e0: k-step bq / 2 of the chunk, dword 2 (bq & 1) + e0 / 2
-                    unsigned w = pack2<T>(gelu_s2(acc1[CUR][th][r0], gp[0]), gelu_s2(acc1[CUR][th][r0 + 1], gp[1]));
-                    asm volatile("" : "+v"(w));
-                    hf[CUR][th][bq >> 1][2 * (bq & 1) + (e0 >> 1)] = w;
-                }
+            for (int u = 0; u < 8; ++u) {
+                const float x = acc1[CUR][th][r0 + u];
+                if constexpr (L == 0) ga[u] = x * x;
+                else if constexpr (L == 1) ga[u] = fminf(ga[u], 36.f);
+                else if constexpr (L == 2) gb[u] = fmaf(ga[u], 0.0010142630555f, -0.1067757240036f);
+                else if constexpr (L == 3) gb[u] = fmaf(gb[u], ga[u], -2.3011213394584f);
+                else if constexpr (L == 4) gb[u] = x * gb[u];
+                else if constexpr (L == 5) gb[u] = __builtin_amdgcn_exp2f(gb[u]);
+                else if constexpr (L == 6) gb[u] = 1.f + gb[u];
+                else if constexpr (L == 7) gb[u] = __builtin_amdgcn_rcpf(gb[u]);
+                else if constexpr (L == 8) gb[u] = x * gb[u];
             }
-            const int fi = m / NH, th = m % NH;
-            if (DO1 && m == NF2 * NH - (NF2 ? 4 : 0)) bias = bias16(b1s + (k + 1) * 32);     // short live range: just ahead of fc1
+            if constexpr (L < 2) VB_PIN8(ga);
+            else if constexpr (L < 9) VB_PIN8(gb);
+            else {
+                u32x4 w;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) w[d] = pack2<T>(gb[2 * d], gb[2 * d + 1]);
+                asm volatile("" : "+v"(w));
+                hf[CUR][th][grp & 1] = w;
+            }
+        };
+        static_assert((TK + S - 1) / S <= 2, "at most two GELU ticks per MFMA slot");
+        vb_static_for<S>([&](auto m_tag) {
+            constexpr int m = decltype(m_tag)::value;
+            constexpr int t_lo = m * TK / S, t_hi = (m + 1) * TK / S;
+#if !(LWDETR_VB_ABLATE & 1)
+            if constexpr (t_lo < t_hi) tick(std::integral_constant<int, t_lo>{});
+            if constexpr (t_lo + 1 < t_hi) tick(std::integral_constant<int, t_lo + 1>{});
+#endif
+            constexpr int fi = m / NH, th = m % NH;
+            if constexpr (DO1 && m == NF2 * NH - (NF2 ? 4 : 0)) bias = bias16(b1s + (k + 1) * 32);     // short live range: just ahead of fc1
             const V8 a = fr[fi % RD];
-            if (fi < NF2) {
-                const int kap = fi / NTI, n = fi % NTI;
+#if LWDETR_VB_ABLATE & 2
+            if constexpr (fi < NF2) { asm volatile("" : "+a"(acc2[fi % NTI][th]) : "v"(a), "v"(hf[NXT][th][fi / NTI])); }
+            else { if constexpr (fi == NF2) acc1[NXT][th] = bias; asm volatile("" : "+v"(acc1[NXT][th]) : "v"(a), "v"(xf[th][fi - NF2])); }
+#else
+            if constexpr (fi < NF2) {
+                constexpr int kap = fi / NTI, n = fi % NTI;
                 acc2[n][th] = Mma32<T>::k16(a, __builtin_bit_cast(V8, hf[NXT][th][kap]), acc2[n][th]);
             } else {
-                const int t = fi - NF2;
-                acc1[NXT][th] = Mma32<T>::k16(a, xf[th][t], t == 0 ? bias : acc1[NXT][th]);
+                constexpr int t = fi - NF2;
+                if constexpr (t == 0) acc1[NXT][th] = Mma32<T>::k16(a, xf[th][t], bias);
+                else acc1[NXT][th] = Mma32<T>::k16(a, xf[th][t], acc1[NXT][th]);
             }
-            if (th == NH - 1 && fi + RD < NF) fr[fi % RD] = fragi(fi + RD);
+#endif
+#if !(LWDETR_VB_ABLATE & 8)
+            if constexpr (th == NH - 1 && fi + RD < NF) fr[fi % RD] = fragi(fi + RD);
+#endif
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -373,8 +462,13 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
             for (int th = 0; th < NH; ++th) acc1[0][th] = Mma32<T>::k16(a, xf[th][t], t == 0 ? bias : acc1[0][th]);
         }
     }
+    VB_TS(5);
     boundary(H0 + 1, H0 + 2, 0);
     iter(I0{}, No{}, Yes{}, 0, H0 + 1, 0);
+    VB_TS(6);
+#ifdef LWDETR_VB_TIMING
+    tt_wait = 0; tt_bar = 0;
+#endif
 #pragma unroll 1
     for (int k = 1; k < NCH - 1; k += 2) {
         boundary(H0 + 2 * k, H0 + 2 * k + 2, 0);
@@ -382,8 +476,13 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         boundary(H0 + 2 * k + 2, H0 + 2 * k + 4, 0);
         iter(I0{}, Yes{}, Yes{}, H0 + 2 * k + 2, H0 + 2 * k + 3, k + 1);
     }
+    VB_TS(7);
+#ifdef LWDETR_VB_TIMING
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) { g_vb_timing[blockIdx.x != 0][wave][13] = tt_wait; g_vb_timing[blockIdx.x != 0][wave][14] = tt_bar; }
+#endif
     boundary(H0 + 2 * NCH - 2, H0 + 2 * NCH - 1, 0);
     iter(I1{}, Yes{}, No{}, H0 + 2 * NCH - 2, 0, NCH - 1);
+    VB_TS(8);
     {   // post-step: fc2(NCH - 1)
         boundary(H0 + 2 * NCH - 1, H0 + 2 * NCH, 0);
 #pragma unroll
@@ -395,6 +494,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         }
     }
 
+    VB_TS(9);
     // ---- epilogue: out = gamma2 * acc (rounded), stores, statistics of the new rows, LN'(x) as the next B operand
     const __amdgpu_buffer_rsrc_t r_o2 = __builtin_amdgcn_make_buffer_rsrc(
         p.out2 ? (void*)((T*)p.out2 + t0 * p.ld2) : (void*)x_w, 0, p.out2 ? (int)(nvalid * p.ld2 * 2) : 0, 0x00020000);
@@ -403,22 +503,31 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     for (int th = 0; th < NH; ++th) {
         float s = 0.f;
 #pragma unroll
-        for (int n = 0; n < NTI; ++n)
+        for (int n = 0; n < NTI; ++n) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int c0 = 32 * n + 8 * b + 4 * h;
-                const f32x4 gg = *(const f32x4*)(g2s + c0);
-                f32x4 o;
+            for (int jb = 0; jb < 2; ++jb) {
+                unsigned pw[4];                     // own packed pairs: registers 8 jb + 2 d, + 1
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = gg[e] * acc2[n][th][4 * b + e];
-                const V4 ov = cvt4<T>(o);
-                const u32x2 ow = __builtin_bit_cast(u32x2, ov);
-                __builtin_amdgcn_raw_buffer_store_b64(ow, r_x, (unsigned)(((32 * th + j) * p.ldx + c0) * 2), 0, 0);
-                if (has_o2) __builtin_amdgcn_raw_buffer_store_b64(ow, r_o2, (unsigned)(((32 * th + j) * p.ld2 + c0) * 2), 0, 0);
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int b = 2 * jb + bb;
+                    const f32x4 gg = *(const f32x4*)(g2s + 32 * n + 8 * b + 4 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float v = to_f32<T>(ov[e]); acc2[n][th][4 * b + e] = v; s += v; }
-                if (b == 3) __builtin_amdgcn_sched_barrier(0);
+                    for (int d = 0; d < 2; ++d) {
+                        const unsigned w = pack2<T>(gg[2 * d] * acc2[n][th][4 * b + 2 * d], gg[2 * d + 1] * acc2[n][th][4 * b + 2 * d + 1]);
+                        pw[2 * bb + d] = w;
+                        const typename Pk<T>::v2 v2 = __builtin_bit_cast(typename Pk<T>::v2, w);
+                        const float v0 = to_f32<T>(v2[0]), v1 = to_f32<T>(v2[1]);
+                        acc2[n][th][4 * b + 2 * d] = v0; acc2[n][th][4 * b + 2 * d + 1] = v1;
+                        s += v0 + v1;
+                    }
+                }
+                const u32x4 ow = vb_rows8(pw[0], pw[1], pw[2], pw[3]);      // channels 32 n + 16 jb + 8 h .. + 7 of token j
+                const int c0 = 32 * n + 16 * jb + 8 * h;
+                __builtin_amdgcn_raw_buffer_store_b128(ow, r_x, (unsigned)(((32 * th + j) * p.ldx + c0) * 2), 0, 0);
+                if (has_o2) __builtin_amdgcn_raw_buffer_store_b128(ow, r_o2, (unsigned)(((32 * th + j) * p.ld2 + c0) * 2), 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (p.stats_out || QKV) {
             s += __shfl_xor(s, 32);
             const float mean = s * (1.f / C);
@@ -451,6 +560,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         }
     }
 
+    VB_TS(10);
     if (QKV) {
         // ---- chained norm1 + QKV of the next block: pieces of 32 features (q: 0 .. NTI-1, k: NTI .. 2 NTI-1, v: 2 NTI ..).
         // Q, K: D[feature][token] -> (B, heads, Tp, hd); V: operands swapped, D[token][feature] -> V^T (B, heads, hd, Tp).
@@ -458,54 +568,63 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc(p.k, 0, (int)p.qkv_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(p.vt, 0, (int)p.qkv_bytes, 0x00020000);
         const int hd = 1 << p.hd_log2;
-        unsigned row_qk[NH], row_v[NH][4];        // element offsets of this lane's token (q, k) / 4-token runs (v^T); ~0u = no token
+        unsigned row_qk[NH];                      // element offset of this lane's token in q / k; 0x7fffffff = no token
 #pragma unroll
         for (int th = 0; th < NH; ++th) {
             const unsigned tok = (unsigned)t0 + 32 * th + j;
             const unsigned img = tok / (unsigned)p.Tp, wi = tok - img * (unsigned)p.Tp;
             row_qk[th] = 32 * th + j < nvalid ? (unsigned)(((long)img * p.heads * p.Tp + wi) << p.hd_log2) : 0x7fffffffu;
+        }
+        // Vector-memory operations newer than the DMA of a step's pieces, for the counted wait (exact: every store below is
+        // issued unconditionally, invalid lanes store out of range): pieces are issued LAG steps ahead (earlier ones during
+        // the hidden loop, before the epilogue's stores).
+        constexpr int XST = NH * NTI * 2, SPS = 2 * NH * 2, LAG = (NSLOT - 2) / 2;
+        const int est = XST * (has_o2 ? 2 : 1);
+        unsigned row_v8[NH][2];                   // v^T: 8-token runs 32 th + 16 jb + 8 h .. of this lane
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int tl = 32 * th + 8 * b + 4 * h;
+        for (int th = 0; th < NH; ++th)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int tl = 32 * th + 16 * jb + 8 * h;
                 const unsigned tk = (unsigned)t0 + tl;
                 const unsigned im = tk / (unsigned)p.Tp, wv = tk - im * (unsigned)p.Tp;
-                row_v[th][b] = tl < nvalid ? (unsigned)((long)im * p.heads * hd * p.Tp + wv) : 0x7fffffffu;
+                row_v8[th][jb] = tl < nvalid ? (unsigned)((long)im * p.heads * hd * p.Tp + wv) : 0x7fffffffu;
             }
-        }
-        constexpr int XST = NH * NTI * 4;         // epilogue stores per wave (x); the tap copy doubles it
-        const int est = XST * (has_o2 ? 2 : 1);
 #pragma unroll 1
         for (int s = 0; s < NP_QKV / 2; ++s) {
-            // stores issued since the DMA of the step's pieces: a lower bound that is exact in the steady state would need the
-            // per-step store count; the epilogue stores (all issued after the DMA of the first QKV pieces) are counted
-            boundary(Q0 + 2 * s, Q0 + 2 * s + 2, s == 0 ? est : 0);
+            boundary(Q0 + 2 * s, Q0 + 2 * s + 2, s < LAG ? est + SPS * s : SPS * LAG);
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const int pi = 2 * s + pp, piece = Q0 + pi;
                 const int sg = pi / NTI, nl0 = (pi - sg * NTI) * 32;
+                f32x16 acc[NH];
                 if (sg < 2) {
                     const f32x16 bias = bias16(bqs + sg * C + nl0);
-                    f32x16 acc[NH];
+                    V8 fr[RD];
+#pragma unroll
+                    for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
 #pragma unroll
                     for (int t = 0; t < KS; ++t) {
-                        const V8 a = frag(piece, t);
+                        const V8 a = fr[t % RD];
 #pragma unroll
                         for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(a, xf[th][t], t == 0 ? bias : acc[th]);
+                        if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     const float sc = sg == 0 ? p.qscale : 1.f;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int f = nl0 + 8 * b + 4 * h, hh = f >> p.hd_log2, dd = f & (hd - 1);
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const int f = nl0 + 16 * jb + 8 * h, hh = f >> p.hd_log2, dd = f & (hd - 1);      // 8 features of one head
                         const unsigned col = (unsigned)(((long)hh * p.Tp << p.hd_log2) + dd);
 #pragma unroll
                         for (int th = 0; th < NH; ++th) {
-                            f32x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = acc[th][4 * b + e] * sc;
-                            const u32x2 ow = __builtin_bit_cast(u32x2, cvt4<T>(o));
-                            const unsigned off = row_qk[th] == 0x7fffffffu ? 0xfffffff0u : (row_qk[th] + col) * 2u;
-                            if (sg == 0) __builtin_amdgcn_raw_buffer_store_b64(ow, r_q, off, 0, 0);
-                            else __builtin_amdgcn_raw_buffer_store_b64(ow, r_k, off, 0, 0);
+                            const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb] * sc, acc[th][8 * jb + 1] * sc),
+                                                      pack2<T>(acc[th][8 * jb + 2] * sc, acc[th][8 * jb + 3] * sc),
+                                                      pack2<T>(acc[th][8 * jb + 4] * sc, acc[th][8 * jb + 5] * sc),
+                                                      pack2<T>(acc[th][8 * jb + 6] * sc, acc[th][8 * jb + 7] * sc));
+                            const unsigned off = row_qk[th] == 0x7fffffffu ? 0x80000000u : (row_qk[th] + col) * 2u;
+                            if (sg == 0) __builtin_amdgcn_raw_buffer_store_b128(ow, r_q, off, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b128(ow, r_k, off, 0, 0);
                         }
                     }
                 } else {
@@ -513,30 +632,33 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
                     f32x16 binit;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) binit[e] = bv;
-                    f32x16 acc[NH];
+                    V8 fr[RD];
+#pragma unroll
+                    for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
 #pragma unroll
                     for (int t = 0; t < KS; ++t) {
-                        const V8 a = frag(piece, t);
+                        const V8 a = fr[t % RD];
 #pragma unroll
                         for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(xf[th][t], a, t == 0 ? binit : acc[th]);
+                        if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     const int f = nl0 + j, hh = f >> p.hd_log2, dd = f & (hd - 1);
                     const unsigned rowb = (unsigned)(((long)hh * hd + dd) * p.Tp);
 #pragma unroll
                     for (int th = 0; th < NH; ++th)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            f32x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = acc[th][4 * b + e];
-                            const u32x2 ow = __builtin_bit_cast(u32x2, cvt4<T>(o));
-                            const unsigned off = row_v[th][b] == 0x7fffffffu ? 0xfffffff0u : (row_v[th][b] + rowb) * 2u;
-                            __builtin_amdgcn_raw_buffer_store_b64(ow, r_v, off, 0, 0);
+                        for (int jb = 0; jb < 2; ++jb) {
+                            const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
+                                                      pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
+                            const unsigned off = row_v8[th][jb] == 0x7fffffffu ? 0x80000000u : (row_v8[th][jb] + rowb) * 2u;
+                            __builtin_amdgcn_raw_buffer_store_b128(ow, r_v, off, 0, 0);
                         }
                 }
             }
         }
     }
+    VB_TS(11);
 }
 
 struct VbLaunchState { bool attr_done; int ncu; };
@@ -564,8 +686,8 @@ int launch_vb(const VbParams& p, hipStream_t st) {
     static const char* env = getenv("LWDETR_VB_GRID");                 // tuning: workgroups (>= need)
     long grid = (need + s.ncu - 1) / s.ncu * s.ncu;
     if (env && atol(env) >= need) grid = atol(env);
-    // 4-token units are dealt by floor(): a wave can get one unit more than the average
-    while (((p.M / 4 + grid * 4 - 1) / (grid * 4)) * 4 > 32 * NH) ++grid;
+    // 8-token units are dealt by floor(): a wave can get one unit more than the average
+    while (((p.M / 8 + grid * 4 - 1) / (grid * 4)) * 8 > 32 * NH) ++grid;
     ProfScope ps(KID_MLP, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C,
                  (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T) + (p.out2 ? 1.0 : 0.0) * p.M * C * sizeof(T), st);
     hipLaunchKernelGGL((vitblock_kernel<T, C, NH, QKV>), dim3((unsigned)grid), dim3(256), lds, st, p);
@@ -593,15 +715,18 @@ extern "C" int lwdetr_vit_block(void* x, long ldx, const void* att, long ldatt, 
                                 void* k_out, void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream) {
     if (!x || !att || !wstream || !vec || M < 0) return LWDETR_ERR_BAD_ARG;
     if (M == 0) return LWDETR_OK;
-    if (M % 4 != 0 || ldx % 4 != 0 || ldatt % 8 != 0 || (out2 && ld2 % 4 != 0)) return LWDETR_ERR_BAD_ARG;
-    if (((uintptr_t)wstream | (uintptr_t)vec | (uintptr_t)att) % 16 != 0 || (uintptr_t)x % 8 != 0) return LWDETR_ERR_BAD_ARG;
+    if (ldx % 8 != 0 || ldatt % 8 != 0 || (out2 && ld2 % 8 != 0)) return LWDETR_ERR_BAD_ARG;
+    if (M % 8 != 0) return LWDETR_ERR_UNSUPPORTED;        // tokens are dealt to waves in runs of 8 (16-byte V^T stores)
+    if (((uintptr_t)wstream | (uintptr_t)vec | (uintptr_t)att) % 16 != 0 || (uintptr_t)x % 16 != 0 || (uintptr_t)out2 % 16 != 0) return LWDETR_ERR_BAD_ARG;
     VbParams p = {};
     p.x = x; p.ldx = ldx; p.att = att; p.ldatt = ldatt; p.wstream = wstream; p.vec = vec; p.out2 = out2; p.ld2 = ld2;
     p.stats_out = stats_out; p.M = M; p.eps = eps; p.eps_next = eps_next; p.qscale = qscale;
     if (has_qkv) {
-        if (!q_out || !k_out || !vt_out || heads <= 0 || hd < 4 || (hd & (hd - 1)) != 0 || heads * hd != C || Tp <= 0 || Tp % 4 != 0)
+        if (!q_out || !k_out || !vt_out || heads <= 0 || hd < 4 || (hd & (hd - 1)) != 0 || heads * hd != C || Tp <= 0 || Tp % 4 != 0 ||
+            ((uintptr_t)q_out | (uintptr_t)k_out | (uintptr_t)vt_out) % 16 != 0)
             return LWDETR_ERR_BAD_ARG;
-        if (M % Tp != 0 || (double)M * C * 2.0 >= 4294967000.0) return LWDETR_ERR_UNSUPPORTED;
+        if (hd < 8 || Tp % 8 != 0) return LWDETR_ERR_UNSUPPORTED;
+        if (M % Tp != 0 || (double)M * C * 2.0 >= 2147483000.0) return LWDETR_ERR_UNSUPPORTED;
         int l2 = 0; while ((1 << l2) < hd) ++l2;
         p.q = q_out; p.k = k_out; p.vt = vt_out; p.heads = heads; p.hd_log2 = l2; p.Tp = Tp;
         p.qkv_bytes = (unsigned)((unsigned long)M * C * 2ul);

@@ -257,13 +257,13 @@ _VB_MIN_GAMMA = 1e-12           # the kernel divides by gamma_1 / gamma_2 (f32):
 
 def vit_block_supported(C_, dtype, hd=None, rows=None) -> bool:
     """Shapes / dtypes lwdetr_vit_block is instantiated for; with ``rows`` the launch-plan choice (LWDETR_VIT_BLOCK=0/1 forces)."""
-    ok = C_ in (192, 384) and dtype in (torch.float16, torch.bfloat16) and (hd is None or (hd >= 4 and hd & (hd - 1) == 0))
+    ok = C_ in (192, 384) and dtype in (torch.float16, torch.bfloat16) and (hd is None or (hd >= 8 and hd & (hd - 1) == 0))
     if not ok or rows is None:
         return ok
     force = os.environ.get("LWDETR_VIT_BLOCK")
     if force in ("0", "1"):
         return force == "1"
-    return rows >= VIT_BLOCK_MIN_ROWS and rows % 4 == 0
+    return rows >= VIT_BLOCK_MIN_ROWS and rows % 8 == 0
 
 
 def vb_kslot_channels(c):

@@ -25,7 +25,7 @@ def _dense(w, x, att, c, eps=1e-6):
     return xn, y
 
 
-@pytest.mark.parametrize("c,nh,t0,nvalid", [(192, 2, 0, 52), (192, 2, 48, 64), (384, 1, 20, 28)])
+@pytest.mark.parametrize("c,nh,t0,nvalid", [(192, 2, 0, 56), (192, 2, 48, 64), (384, 1, 24, 24)])
 def test_pack_vit_block_matches_dense_through_lane_emulation(c, nh, t0, nvalid):
     from lwdetr_amd import kernels as K
     w = _weights(c)
