@@ -103,6 +103,7 @@ struct VbParams {
 #define VB_VMW(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // wait until at most n vector-memory operations of this wave are outstanding (n wave-uniform, rounded down to a multiple of 3)
 __device__ __forceinline__ void vb_wait_le(int n) {
+    if (n == 12) { VB_VMW(12); return; }            // the hidden loop's steady state (C = 192; 4 pieces x 3 in flight)
     if (n >= 63) { VB_VMW(63); return; }
     switch (n / 3) {
         case 0: VB_VMW(0); break;   case 1: VB_VMW(3); break;   case 2: VB_VMW(6); break;   case 3: VB_VMW(9); break;
@@ -114,6 +115,12 @@ __device__ __forceinline__ void vb_wait_le(int n) {
     }
 }
 
+#define VB_GELU_C0 (-2.3087653f)
+#define VB_GELU_C1 (-0.10012561f)
+// x * sigmoid form with a two-term exponent, coefficients fitted (minimax on [-10, 10]) to the exact erf GELU: max |error| 2.7e-4
+__device__ __forceinline__ float vb_gelu16(float x) {
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * fmaf(x * x, VB_GELU_C1, VB_GELU_C0)));
+}
 // GELU for 16-bit storage (common.h:gelu_fast16) split into three stages of 3 VALU-class instructions per value, so that the
 // hidden loop can hand them out between MFMAs: s0 -> (x2, p), s1 -> e = exp2(x * (p x2 + c0)), s2 -> x * rcp(1 + e).
 __device__ __forceinline__ void gelu_s0(float x, float& x2, float& p) {
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     constexpr int VEC_B = (VEC_F * 4 + 4095) / 4096 * 4096, VEC_DPW = VEC_B / 4096;
     constexpr int NP_PROJ = NTI, NP_HID = 2 * NCH, NP_QKV = QKV ? 3 * NTI : 0, NP = NP_PROJ + NP_HID + NP_QKV;
     constexpr int H0 = NP_PROJ, Q0 = NP_PROJ + NP_HID;
-    constexpr int RD = NH == 2 ? 3 : 5;         // fragment read-ahead (fragments)
+    constexpr int RD = NH == 2 ? 4 : 8;         // fragment read-ahead: an LDS round trip is ~170 cycles under load (see vitblock8_kernel)
     static_assert(DPW % 3 == 0 && VEC_DPW >= 1, "wait counts are kept in multiples of 3");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const float* vec = (const float*)(smem + NSLOT * PIECE_B);
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
             }
         __builtin_amdgcn_sched_barrier(0);
         v += __shfl_xor(v, 32);
-        const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps);
+        const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps), nmr = -mean * rstd;
 #pragma unroll
         for (int n = 0; n < NTI; ++n) {
             u32x4 w0, w1;
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
                     float v0, v1; unpack2(xp[n][2 * b + d], v0, v1);
                     na[4 * b + 2 * d] = fmaf(v0, rg[2 * d], b2[2 * d]);
                     na[4 * b + 2 * d + 1] = fmaf(v1, rg[2 * d + 1], b2[2 * d + 1]);
-                    const unsigned nw = pack2<T>((v0 - mean) * rstd, (v1 - mean) * rstd);
+                    const unsigned nw = pack2<T>(fmaf(v0, rstd, nmr), fmaf(v1, rstd, nmr));
                     if (b < 2) w0[2 * b + d] = nw; else w1[2 * (b - 2) + d] = nw;
                 }
             }
@@ -384,8 +391,8 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         // GELU of chunk k in "layer ticks": a tick applies ONE instruction of the GELU chain to the 8 values of a group (one
         // (token half, k-step) B operand of fc2), so consecutive instructions of a chain sit a whole MFMA slot apart - with one
         // wave per SIMD nothing else hides VALU / transcendental result latency (3-stage ticks on 2 values measured 1.8 us per
-        // iteration, most of it dependency stalls). 10 layers x 2 NH groups of ticks over the iteration's MFMA slots.
-        constexpr int NG = 2 * NH, TK = 10 * NG;
+        // iteration). 8 layers x 2 NH groups of ticks over the iteration's MFMA slots.
+        constexpr int NG = 2 * NH, NL = 8, TK = NL * NG;
         auto fragi = [&](int i) -> V8 { return i < NF2 ? frag(p2, i) : frag(p1, i - NF2); };
         f32x16 bias = {};
         V8 fr[RD];
@@ -393,23 +400,23 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
         for (int i = 0; i < RD; ++i) if (i < NF) fr[i] = fragi(i);
         float ga[8], gb[8];
 #define VB_PIN8(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
+        // GELU for 16-bit storage in its two-term form x * sigmoid(-x (c0 + c1 x^2)) (vb_gelu16, max |error| 2.7e-4 - a tenth of
+        // what 16-bit arithmetic costs end to end): 7 instructions per value instead of 9
         auto tick = [&](auto ti_tag) {
-            constexpr int ti = decltype(ti_tag)::value, grp = ti / 10, L = ti % 10, th = grp >> 1, r0 = 8 * (grp & 1);
+            constexpr int ti = decltype(ti_tag)::value, grp = ti / NL, L = ti % NL, th = grp >> 1, r0 = 8 * (grp & 1);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float x = acc1[CUR][th][r0 + u];
                 if constexpr (L == 0) ga[u] = x * x;
-                else if constexpr (L == 1) ga[u] = fminf(ga[u], 36.f);
-                else if constexpr (L == 2) gb[u] = fmaf(ga[u], 0.0010142630555f, -0.1067757240036f);
-                else if constexpr (L == 3) gb[u] = fmaf(gb[u], ga[u], -2.3011213394584f);
-                else if constexpr (L == 4) gb[u] = x * gb[u];
-                else if constexpr (L == 5) gb[u] = __builtin_amdgcn_exp2f(gb[u]);
-                else if constexpr (L == 6) gb[u] = 1.f + gb[u];
-                else if constexpr (L == 7) gb[u] = __builtin_amdgcn_rcpf(gb[u]);
-                else if constexpr (L == 8) gb[u] = x * gb[u];
+                else if constexpr (L == 1) gb[u] = fmaf(ga[u], VB_GELU_C1, VB_GELU_C0);
+                else if constexpr (L == 2) gb[u] = x * gb[u];
+                else if constexpr (L == 3) gb[u] = __builtin_amdgcn_exp2f(gb[u]);
+                else if constexpr (L == 4) gb[u] = 1.f + gb[u];
+                else if constexpr (L == 5) gb[u] = __builtin_amdgcn_rcpf(gb[u]);
+                else if constexpr (L == 6) gb[u] = x * gb[u];
             }
-            if constexpr (L < 2) VB_PIN8(ga);
-            else if constexpr (L < 9) VB_PIN8(gb);
+            if constexpr (L < 1) VB_PIN8(ga);
+            else if constexpr (L < 7) VB_PIN8(gb);
             else {
                 u32x4 w;
 #pragma unroll
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { const float dl = acc2[n][th][e] - mean; v += dl * dl; }
             v += __shfl_xor(v, 32);
-            const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps_next);
+            const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps_next), nmr = -mean * rstd;
             if (p.stats_out && h == 0 && 32 * th + j < nvalid) {
                 float* so = p.stats_out + 2 * (t0 + 32 * th + j);
                 so[0] = mean; so[1] = rstd;
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
 #pragma unroll
                             for (int d = 0; d < 4; ++d) {
                                 const int r = (2 * be + (d >> 1)) * 4 + (d & 1) * 2;
-                                w[d] = pack2<T>((acc2[n][th][r] - mean) * rstd, (acc2[n][th][r + 1] - mean) * rstd);
+                                w[d] = pack2<T>(fmaf(acc2[n][th][r], rstd, nmr), fmaf(acc2[n][th][r + 1], rstd, nmr));
                             }
                             xf[th][2 * n + be] = __builtin_bit_cast(V8, w);
                         }
@@ -611,17 +618,20 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
                         if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    const float sc = sg == 0 ? p.qscale : 1.f;
+                    if (sg == 0) {                      // Q is pre-scaled (wave-uniform branch: K pieces skip the 16 NH multiplies)
+#pragma unroll
+                        for (int th = 0; th < NH; ++th)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[th][e] *= p.qscale;
+                    }
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb) {
                         const int f = nl0 + 16 * jb + 8 * h, hh = f >> p.hd_log2, dd = f & (hd - 1);      // 8 features of one head
                         const unsigned col = (unsigned)(((long)hh * p.Tp << p.hd_log2) + dd);
 #pragma unroll
                         for (int th = 0; th < NH; ++th) {
-                            const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb] * sc, acc[th][8 * jb + 1] * sc),
-                                                      pack2<T>(acc[th][8 * jb + 2] * sc, acc[th][8 * jb + 3] * sc),
-                                                      pack2<T>(acc[th][8 * jb + 4] * sc, acc[th][8 * jb + 5] * sc),
-                                                      pack2<T>(acc[th][8 * jb + 6] * sc, acc[th][8 * jb + 7] * sc));
+                            const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
+                                                      pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
                             const unsigned off = row_qk[th] == 0x7fffffffu ? 0x80000000u : (row_qk[th] + col) * 2u;
                             if (sg == 0) __builtin_amdgcn_raw_buffer_store_b128(ow, r_q, off, 0, 0);
                             else __builtin_amdgcn_raw_buffer_store_b128(ow, r_k, off, 0, 0);

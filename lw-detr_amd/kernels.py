@@ -284,12 +284,14 @@ def _vb_frags(w32):
     return w32.reshape(32, -1, 2, 8).permute(1, 2, 0, 3).contiguous()
 
 
-def pack_vit_block(wp, bp, g1, w1, b1, w2, b2, g2, ln2_w, ln2_b, dtype, qkv=None):
+def pack_vit_block(wp, bp, g1, w1, b1, w2, b2, g2, ln2_w, ln2_b, dtype, qkv=None, order=None):
     """Host-side packing for lwdetr_vit_block (f32 master tensors in): returns (stream of ``dtype``, vec f32).
 
     stream = pieces of 32 rows x C (or C x 32) in consumption order, every piece KS = C/16 fragments of 1 KB in MFMA lane
-    order: Wp tiles 0..C/32-1 (natural k order: the attention rows come straight from memory); W1c(0), W1c(1), then
-    (W2c(k-1), W1c(k+1)) for k = 1..NCH-2, W2c(NCH-2), W2c(NCH-1) (W1 = fc1 * ln2_w with its columns in k-slot order,
+    order: Wp tiles 0..C/32-1 (natural k order: the attention rows come straight from memory); then the hidden pieces in the
+    order of the kernel form - "pipelined" (C = 384, 4-wave kernel): W1c(0), W1c(1), (W2c(k-1), W1c(k+1)) for k = 1..NCH-2,
+    W2c(NCH-2), W2c(NCH-1); "alternating" (C = 192, 8-wave kernel): pairs (W1c(0), pad), (W2c(k), W1c(k+1)) for k = 0..NCH-2, (W2c(NCH-1), pad)
+    (W1 = fc1 * ln2_w with its columns in k-slot order,
     W2c(k) = fc2[:, 32k..32k+31] as fragments (k-step, output tile) with the hidden units in accumulator order); optionally
     the next block's Wqkv' tiles (``qkv`` = (wqkv, q_bias, v_bias, ln1_w, ln1_b), LayerNorm affine folded, k-slot order).
     vec = b1' | bp | g1 | 1/g1 | b2 | 1/g2 | g2 | bqkv' zero-padded to a multiple of 4 KB."""
@@ -312,10 +314,19 @@ def pack_vit_block(wp, bp, g1, w1, b1, w2, b2, g2, ln2_w, ln2_b, dtype, qkv=None
         blk = w2[:, 32 * k:32 * k + 32].reshape(nti, 32, 2, 2, 2, 4)           # n, i, kap, b', h, e
         return blk.permute(2, 0, 4, 1, 3, 5).reshape(2 * nti, 2, 32, 8).contiguous()   # (kap, n), h, i, (b', e)
 
-    pieces += [w1c(0), w1c(1)]
-    for k in range(1, nch - 1):
-        pieces += [w2c(k - 1), w1c(k + 1)]
-    pieces += [w2c(nch - 2), w2c(nch - 1)]
+    order = order or "pipelined"        # "alternating": the 8-wave experiment of round 3 (profiles/r3b_*), not in the product
+    if order == "pipelined":
+        pieces += [w1c(0), w1c(1)]
+        for k in range(1, nch - 1):
+            pieces += [w2c(k - 1), w1c(k + 1)]
+        pieces += [w2c(nch - 2), w2c(nch - 1)]
+    else:
+        assert order == "alternating"      # pairs of pieces, one pair per MFMA task: two zero pad pieces
+        pad = torch.zeros_like(w1c(0))
+        pieces += [w1c(0), pad]
+        for k in range(nch - 1):
+            pieces += [w2c(k), w1c(k + 1)]
+        pieces += [w2c(nch - 1), pad]
     bq = torch.zeros(3 * c)
     if qkv is not None:
         wqkv, q_bias, v_bias, ln1_w, ln1_b = map(f, qkv)

@@ -499,7 +499,7 @@ def test_vit_block_rounding_points_fp64():
     inputs / weights, x1 and the output rounded to f16, f32 accumulation otherwise): the benchmarked kernel itself meets the
     1e-3 bar of the fp32 parity gate when its inputs are exactly representable."""
     from lwdetr_amd import kernels as K
-    from tests.vitblock_sim import gelu_fast16
+    from tests.vitblock_sim import gelu_vb16
     c, m, dtype = 192, 12800, torch.float16
     r16 = lambda t: t.to(dtype).double()
     x, att = r16(_rand(m, c, seed=1) * 2 + 0.3), r16(_rand(m, c, seed=9))
@@ -514,7 +514,7 @@ def test_vit_block_rounding_points_fp64():
     x1 = r16((x + g1.float().double() * (att @ wp16.t() + bp.float().double())).float())
     ln = r16(((x1 - x1.mean(1, keepdim=True)) / (x1.var(1, unbiased=False, keepdim=True) + 1e-6).sqrt()).float())
     hid = ln @ w116.t() + b1.float().double()
-    hid = r16(torch.from_numpy(gelu_fast16(hid.cpu().numpy())).to(_dev()).float())
+    hid = r16(torch.from_numpy(gelu_vb16(hid.cpu().numpy())).to(_dev()).float())
     ref = r16((x1 + g2.float().double() * (hid @ w216.t() + b2.float().double())).float())
     xx = x.to(dtype).clone()
     K.VitBlockOp(xx, att.to(dtype), stream.to(_dev()), vec.to(_dev()), m, c, 1e-6)()

@@ -25,8 +25,9 @@ def _dense(w, x, att, c, eps=1e-6):
     return xn, y
 
 
-@pytest.mark.parametrize("c,nh,t0,nvalid", [(192, 2, 0, 56), (192, 2, 48, 64), (384, 1, 24, 24)])
-def test_pack_vit_block_matches_dense_through_lane_emulation(c, nh, t0, nvalid):
+@pytest.mark.parametrize("c,nh,t0,nvalid,order", [(192, 1, 8, 32, "alternating"), (192, 1, 48, 24, "alternating"), (192, 2, 48, 64, "pipelined"),
+                                                    (384, 1, 24, 24, "pipelined")])
+def test_pack_vit_block_matches_dense_through_lane_emulation(c, nh, t0, nvalid, order):
     from lwdetr_amd import kernels as K
     w = _weights(c)
     m, tp, heads = 120, 60, c // 32
@@ -35,12 +36,11 @@ def test_pack_vit_block_matches_dense_through_lane_emulation(c, nh, t0, nvalid):
     x = torch.randn(m, c, generator=g, dtype=torch.float64) * 1.5 + 0.2
     att = torch.randn(m, c, generator=g, dtype=torch.float64)
     stream, vec = K.pack_vit_block(w["wp"], w["bp"], w["g1"], w["w1"], w["b1"], w["w2"], w["b2"], w["g2"], w["ln2_w"], w["ln2_b"],
-                                   torch.float64, qkv=(w["wqkv"], w["qb"], w["vb"], w["ln1_w"], w["ln1_b"]))
+                                   torch.float64, qkv=(w["wqkv"], w["qb"], w["vb"], w["ln1_w"], w["ln1_b"]), order=order)
     nti = c // 32
-    assert stream.numel() * 2 == K._nat.lib().lwdetr_vit_block_stream_bytes(c, 1) if K._nat.is_built() else True
-    assert stream.numel() == (nti + 8 * nti + 3 * nti) * (c // 16) * 512
+    assert stream.numel() == (nti + 8 * nti + 3 * nti + (2 if order == "alternating" else 0)) * (c // 16) * 512
     out, writes = simulate_wave(stream.numpy(), vec.numpy(), x.numpy(), att.numpy(), t0, nvalid, c, nh, 1e-6, 1e-6,
-                                qkv=dict(heads=heads, hd=hd, Tp=tp, qscale=0.37))
+                                qkv=dict(heads=heads, hd=hd, Tp=tp, qscale=0.37), order=order)
     xn, y = _dense(w, x, att, c)
     assert np.abs(out - xn[t0:t0 + nvalid].numpy()).max() < 5e-6       # the packer keeps f32 master copies
     # every q / k / v^T element of the wave's tokens is written exactly once, at the address of the HEADS / HEADS_T layouts

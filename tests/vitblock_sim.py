@@ -30,7 +30,12 @@ def gelu_fast16(x):
     return x / (1.0 + np.exp2(x * p))
 
 
-def simulate_wave(stream, vec, x, att, t0, nvalid, C, NH, eps, eps_next, qkv=None):
+def gelu_vb16(x):
+    """The block kernel's two-term form (vitblock.hip:vb_gelu16)."""
+    return x / (1.0 + np.exp2(x * (-2.3087653 - 0.10012561 * x * x)))
+
+
+def simulate_wave(stream, vec, x, att, t0, nvalid, C, NH, eps, eps_next, qkv=None, order="pipelined"):
     """One wave of the kernel: tokens [t0, t0 + nvalid) of x / att (M, C). Returns (new rows (nvalid, C), dict of q/k/v writes).
     qkv = dict(heads, hd, Tp, qscale) or None; writes are returned as {("q"|"k"|"v", flat element index): value}."""
     KS, NTI, NCH = C // 16, C // 32, C // 8
@@ -117,13 +122,21 @@ def simulate_wave(stream, vec, x, att, t0, nvalid, C, NH, eps, eps_next, qkv=Non
 
     acc1 = {0: fc1(H0, 0)}
     hfs = {}
-    for k in range(NCH):
-        hfs[k] = gelu_to_hf(acc1[k])
-        if k >= 1:
-            fc2(H0 + 2 * k, hfs[k - 1])                      # W2c(k-1)
-        if k + 1 < NCH:
-            acc1[k + 1] = fc1(H0 + 2 * k + 1, k + 1)         # W1c(k+1)
-    fc2(H0 + 2 * NCH - 1, hfs[NCH - 1])
+    if order == "pipelined":        # the 4-wave kernel: iteration k = GELU(k) beside fc2(k-1) and fc1(k+1)
+        for k in range(NCH):
+            hfs[k] = gelu_to_hf(acc1[k])
+            if k >= 1:
+                fc2(H0 + 2 * k, hfs[k - 1])                      # W2c(k-1)
+            if k + 1 < NCH:
+                acc1[k + 1] = fc1(H0 + 2 * k + 1, k + 1)         # W1c(k+1)
+        fc2(H0 + 2 * NCH - 1, hfs[NCH - 1])
+    else:                           # the 8-wave kernel: GELU(k) task, then the MFMA task fc2(k) + fc1(k+1); pairs, 2 pad pieces
+        for k in range(NCH):
+            hfs[k] = gelu_to_hf(acc1[k])
+            fc2(H0 + 2 + 2 * k, hfs[k])                          # W2c(k): first piece of pair 4 + k
+            if k + 1 < NCH:
+                acc1[k + 1] = fc1(H0 + 3 + 2 * k, k + 1)         # W1c(k+1): second piece
+        Q0 += 2
 
     out = np.zeros((nvalid, C))
     writes = {}
