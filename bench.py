@@ -147,9 +147,31 @@ def cpu_baseline(size, res):
     what = ("the unmodified reference (oracle/ref_shims.py import shims)" if kind == "reference" else
             "oracle/lwdetr_torch.py (CPU restatement of the reference PyTorch path; /root/reference is absent on this box)")
     return {"value": round(best[0], 2), "unit": "images/sec", "cores": best[1] * best[2], "kind": kind,
-            "cpu_model": _cpu_model_string(), "host_cores": cores,
+            "cpu_model": _cpu_model_string(), "host_cores": cores, "host": _host_cpu_facts(),
             "sample": f"{best[1]} worker process(es) x {best[2]} threads, ~6 s of batch-2 forwards each at {res}x{res}, "
                       f"fp32, {what}", "sweep": sweep}
+
+
+def _host_cpu_facts():
+    """What the box actually grants this process: cgroup CPU quota, affinity / online CPUs, load average (the baseline on the
+    256-thread GPU host scales far below linearly; these are the facts that explain it, recorded instead of guessed)."""
+    facts = {"affinity": len(os.sched_getaffinity(0)), "nproc_online": os.cpu_count()}
+    for name, path in (("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max"), ("cgroup_v1_cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"),
+                       ("cgroup_v1_cfs_period_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"), ("cpuset_effective", "/sys/fs/cgroup/cpuset.cpus.effective")):
+        try:
+            facts[name] = open(path).read().strip()[:80]
+        except OSError:
+            pass
+    try:
+        facts["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except OSError:
+        pass
+    try:
+        st = {ln.split()[0]: ln.split()[1:] for ln in open("/sys/fs/cgroup/cpu.stat")}
+        facts["cgroup_nr_throttled"] = st.get("nr_throttled", [None])[0]
+    except OSError:
+        pass
+    return facts
 
 
 def self_launch(a):
@@ -211,15 +233,19 @@ def main():
     pp = post["bbox"]
     images = synth_images(a.batch, a.res, a.res, seed=1234 + rank).to(dev).to(T)
     sizes = torch.tensor([[480.0, 640.0]] * a.batch, device=dev)
-    gathered = torch.empty(world * a.batch, cfg.num_select, 6, dtype=torch.float32, device=dev) if world > 1 else None
+    # under a launcher (torchrun) the process group exists even with one rank: the collective then runs on the backend too, so
+    # a one-rank torchrun of this file exercises RCCL exactly as an N-rank job does (tests/test_gpu_dist.py)
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+    backend = torch.distributed.get_backend() if grouped else None
+    gathered = torch.empty(world * a.batch, cfg.num_select, 6, dtype=torch.float32, device=dev) if grouped else None
 
     def step():
         out = model(images)
         det = pp.select_packed(out["pred_logits"], out["pred_boxes"], sizes)      # PostProcess -> (B, K, 6) records
-        return ldist.all_gather_detections(det, gathered)
+        return ldist.all_gather_detections(det, gathered, always_collective=grouped)
 
     def barrier():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -260,7 +286,7 @@ def main():
         "config": {"workload": f"LW-DETR-{a.size} inference forward + PostProcess, {a.res}x{a.res}, batch {a.batch}/GPU, "
                                f"{a.dtype}, random-init weights (synthetic COCO-shaped input)",
                    "global_batch": world * a.batch, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
-                   "collective": "all_gather_into_tensor of (B,K,6) f32 detections" if world > 1 else "none"},
+                   "collective": "all_gather_into_tensor of (B,K,6) f32 detections" if grouped else "none", "backend": backend},
     }
     if dt_nog is not None:
         result["ms_per_step_without_all_gather"] = round(dt_nog / a.steps * 1e3, 3)
@@ -294,7 +320,7 @@ def main():
                     "frac": round(ach / PEAK_HBM_GBS, 4)}
         # HBM bytes per launch need rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs): they are not
         # measurable from inside this process, so the figure is read from the tracked summary of those passes for
-        # this workload (tools/profile_round.sh -> profiles/hbm_traffic*.json) and labelled as such
+        # this workload (tools/profile_round.sh -> profiles/pmc_summary_<workload>.json) and labelled as such
         traffic, tsrc = None, None
         wl = f"{a.size}_b{a.batch}_{a.res}_{a.dtype}"
         tfp = os.path.join(ROOT, "profiles", f"pmc_summary_{wl}.json")
@@ -345,8 +371,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.barrier()          # rank 0 may still be in its (untimed) roofline pass: leave together
+    if grouped:
+        torch.distributed.barrier()          # rank 0 may still be in its (untimed) roofline / latency passes: leave together
         torch.distributed.destroy_process_group()
 
 

@@ -157,7 +157,8 @@ int lwdetr_layernorm_chain(const void* x, long ldx, const float* gamma1, const f
  * lwdetr_ffn_finish: x + b2 + sum of the partial slabs (rounded to the 16-bit dtype, as the unfused GEMM epilogue rounds),
  * out1 = LN1(.), optionally out2 = LN2(out1). w1 (hid, C) plain row-major; w2_chunked (hid/32, C, 32) as for
  * lwdetr_mlp_fused. C in {256, 384}, hid % 64 == 0, 16-bit dtypes. lwdetr_ffn_splits returns the number of slabs the
- * launch for (M, C, hid) writes (> 0), or -error. */
+ * launch for (M, C, hid) writes (> 0), or -error. lwdetr_ffn_finish: out1 MAY alias x (every row is read completely before it is
+ * written; the engine updates the decoder stream in place); out2 must not alias x or out1. */
 int lwdetr_ffn_splits(long M, int C, int hid, int dtype);
 int lwdetr_ffn_partial(const void* x, long ldx, const void* w1, const float* b1, const void* w2_chunked, float* partial, long M,
                        int C, int hid, int dtype, void* hip_stream);

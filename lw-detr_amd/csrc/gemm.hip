@@ -626,114 +626,7 @@ __device__ __forceinline__ void gdma16(const void* src, const void* lds_wave_bas
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
 }
 
-template <typename T, int BM, int NST>
-__global__ __launch_bounds__(256) void gemm_apanel_kernel(const lwdetr_gemm_desc d) {
-    constexpr int EPC = 8, BN = 64, KB = 64, SLOTS = 8, RP = 8;
-    constexpr int A_MY = BM / RP / 4, B_MY = BN / RP / 4;        // DMA pieces per wave: per A column block / per W stage
-    constexpr int WM = BM / 2, WN = BN / 2, TT = WM / 16, FT = WN / 16;
-    constexpr int STAGE = BN * KB;
-    typedef typename Vec<T>::v8 V8;
-    static_assert(sizeof(T) == 2, "");
-    extern __shared__ __attribute__((aligned(16))) char apanel_smem[];
-    T* panel = (T*)apanel_smem;                                  // [K / 64][BM][64]
-    const int nkb = d.K / KB;
-    T* ring = panel + (long)nkb * BM * KB;                       // [NST][BN][64]
-    T* stage_area = ring + NST * STAGE;                          // f32 epilogue staging, 64 x (BN + 4) floats
 
-    const long m0 = (long)blockIdx.x * BM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const T* __restrict__ A = (const T*)d.A;
-    const T* __restrict__ W = (const T*)d.W;
-    const T* zero = (const T*)g_zero16;
-    const int prow = lane / SLOTS, pslot = lane % SLOTS;
-
-    // ---- A panel: every column block, this wave's pieces
-#pragma unroll
-    for (int k = 0; k < A_MY; ++k) {
-        const int piece = wave + 4 * k;
-        const long m = m0 + RP * piece + prow;
-        const int ccol = (pslot ^ (((piece * RP + prow) >> 1) & 7)) * EPC;
-        const T* src = m < d.M ? A + m * d.lda + ccol : nullptr;
-        for (int kb = 0; kb < nkb; ++kb)
-            gdma16(src ? src + kb * KB : zero, panel + ((long)kb * BM + piece * RP) * KB);
-    }
-    // ---- W ring: stage s = (column tile tn, column block kb) in walking order
-    const int tiles_n = (d.N + BN - 1) / BN;
-    const int nstage = tiles_n * nkb;
-    int w_cc[B_MY], w_row[B_MY];
-#pragma unroll
-    for (int k = 0; k < B_MY; ++k) {
-        const int piece = wave + 4 * k;
-        w_cc[k] = (pslot ^ (((piece * RP + prow) >> 1) & 7)) * EPC;
-        w_row[k] = RP * piece + prow;
-    }
-    auto stage = [&](int s) {            // always B_MY pieces; stages past the end read the zero page
-        T* Bs = ring + (s % NST) * STAGE;
-        const int tn = s / nkb, kb = s - tn * nkb;
-#pragma unroll
-        for (int k = 0; k < B_MY; ++k) {
-            const int n = tn * BN + w_row[k];
-            const T* src = (s < nstage && n < d.N) ? W + (long)n * d.K + kb * KB + w_cc[k] : zero;
-            gdma16(src, Bs + (wave + 4 * k) * 64 * EPC);
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s) stage(s);
-
-    int pc[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) pc[c] = ((c * 4 + g) ^ ((l15 >> 1) & 7)) * EPC;
-    bool drained = false;                // true right after an epilogue: stores are in flight, counted waits are unsafe
-    int s = 0;
-    for (int tn = 0; tn < tiles_n; ++tn) {
-        const int n0 = tn * BN;
-        int si = 0;
-#pragma unroll
-        for (int q = 1; q < 3; ++q) if (q < d.nseg && n0 >= d.seg[q].n_begin) si = q;
-        const lwdetr_gemm_seg& sg = d.seg[si];
-        const bool col_orient = sg.mode == LWDETR_OUT_HEADS_T;
-        f32x4 acc[FT][TT];
-#pragma unroll
-        for (int f = 0; f < FT; ++f)
-#pragma unroll
-            for (int t = 0; t < TT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kb = 0; kb < nkb; ++kb, ++s) {
-            if (drained || s == 0) { wait_vmcnt<0>(); drained = false; }      // s == 0: the A panel too (issued first anyway)
-            else wait_vmcnt<(NST - 2) * B_MY>();
-            __builtin_amdgcn_s_barrier();
-            stage(s + NST - 1);
-            const T* As = panel + (long)kb * BM * KB;
-            const T* Bs = ring + (s % NST) * STAGE;
-            V8 xf[2][TT], wf[2][FT];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                for (int t = 0; t < TT; ++t) xf[c][t] = *(const V8*)(As + (wm * WM + t * 16 + l15) * KB + pc[c]);
-#pragma unroll
-                for (int f = 0; f < FT; ++f) wf[c][f] = *(const V8*)(Bs + (wn * WN + f * 16 + l15) * KB + pc[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (!col_orient) {
-#pragma unroll
-                    for (int f = 0; f < FT; ++f)
-#pragma unroll
-                        for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(wf[c][f], xf[c][t], acc[f][t]);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < FT; ++f)
-#pragma unroll
-                        for (int t = 0; t < TT; ++t) acc[f][t] = Mma<T>::k32(xf[c][t], wf[c][f], acc[f][t]);
-                }
-            }
-        }
-        gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, stage_area, m0, n0);
-        drained = true;
-    }
-    wait_vmcnt<0>();                     // the dummy tail pieces target LDS: they must land before the workgroup retires
-}
 
 // ---- large-tile variant for the compute-bound GEMMs (C = 384 / 768 models: K >= 384, tens of thousands of rows) -----
 // 512 threads = 8 waves, block tile 256 x BN (BN = 256: 2 x 4 waves of 128 x 64; BN = 128: 4 x 2 waves of 64 x 64),
@@ -1030,12 +923,14 @@ int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     constexpr size_t ring = (size_t)NST * (256 + BN) * KB * sizeof(T);
     constexpr size_t stg = (size_t)(BN == 128 ? 4 : 2) * (64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
     constexpr size_t lds = ring > stg ? ring : stg;
-    static bool done = false;
-    if (!done) {
-        if (hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return LWDETR_ERR_LAUNCH;
-        done = true;
-    }
+    // per device (a process may drive several GPUs); a device that refuses the 160 KB request keeps the 64 x 64 ring kernel:
+    // LWDETR_ERR_UNSUPPORTED tells try_launch_big to fall through
+    static signed char state[16] = {};          // 0 = not asked yet, 1 = granted, -1 = refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_UNSUPPORTED;
+    if (state[dev] == 0)
+        state[dev] = hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : -1;
+    if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
     const long nwg = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(512), lds, st, d);
     return lwdetr_check_launch();
@@ -1069,11 +964,13 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
         for (int s = 0; s < d.nseg; ++s) if (d.seg[s].n_begin % bn != 0) return LWDETR_OK;
         const long tiles = ((d.M + 255) / 256) * ((d.N + bn - 1) / bn);
         if (mode == 1 && !(d.K >= 384 && d.N >= 192 && (d.M >= 16384 || (d.K >= 960 && tiles >= 96)))) return LWDETR_OK;
-        taken = true;
         const int variant = mode >= 10 ? mode : 0;     // tuning: 32 / 64 = stage depth (ring 4 / 2 deep)
-        if (bn == 256) return variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st);
-        if (bn == 192) return launch_big<T, 192, 64, 2, AMODE>(d, st);
-        return variant == 32 ? launch_big<T, 128, 32, 4, AMODE>(d, st) : launch_big<T, 128, 64, 3, AMODE>(d, st);
+        int rc;
+        if (bn == 256) rc = variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st);
+        else if (bn == 192) rc = launch_big<T, 192, 64, 2, AMODE>(d, st);
+        else rc = variant == 32 ? launch_big<T, 128, 32, 4, AMODE>(d, st) : launch_big<T, 128, 64, 3, AMODE>(d, st);
+        taken = rc != LWDETR_ERR_UNSUPPORTED;          // refused LDS size: the caller launches the ring kernel instead
+        return taken ? rc : LWDETR_OK;
     }
 }
 
@@ -1119,32 +1016,11 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
             // k-loop is not where these short-K GEMMs spend their time. Kept selectable for tuning (LWDETR_GEMM_KB=64).
             static const char* kb_env = getenv("LWDETR_GEMM_KB");
             const bool kb64 = kb_env && atoi(kb_env) == 64 && d.K % 64 == 0 && (AMODE != LWDETR_A_CONV3x3 || d.conv_cin % 64 == 0);
-            // A-panel-resident schedule (LWDETR_GEMM_APANEL=64|128 selects it and its row tile; OFF by default). Measured on
-            // MI355X, M = 51200: QKV (N 576, K 192) 51 -> 73 / 106 us, projector 1x1 (N 256, K 768) 60 -> 137 us, value
-            // projection (N 768, K 256) 62 -> 93 / 124 us. It cuts what a CU pulls in by 2-3x and loses anyway: with 66-108 KB
-            // of LDS a CU holds one or two workgroups, whose column tiles, epilogues and store latencies then run back to
-            // back, where the 64 x 64 grid keeps 4-5 independent workgroups per CU in flight. These GEMMs are bound by
-            // latency hiding (occupancy), not by CU ingress.
-            static const char* ap_env = getenv("LWDETR_GEMM_APANEL");
-            const bool ap_ok = AMODE == LWDETR_A_PLAIN && d.K % 64 == 0 && d.K <= 768 && d.N > 64 && d.M >= 32768 &&
-                               ap_env && (atoi(ap_env) == 64 || atoi(ap_env) == 128);
-            if (ap_ok) {
-                const int bm_env = ap_env ? atoi(ap_env) : 0;
-                const int bm = (bm_env == 64 || bm_env == 128) && (size_t)d.K * bm_env * sizeof(T) <= 100 * 1024 ? bm_env
-                                                                                                              : (d.K <= 384 ? 128 : 64);
-                const size_t lds = ((size_t)d.K * bm + 3 * 64 * 64) * sizeof(T) + 64 * (64 + 4) * sizeof(float);
-                const unsigned blocks = (unsigned)((d.M + bm - 1) / bm);
-                if (bm == 128) {
-                    static bool done = false;
-                    if (!done) { if (hipFuncSetAttribute((const void*)gemm_apanel_kernel<T, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return LWDETR_ERR_LAUNCH; done = true; }
-                    hipLaunchKernelGGL((gemm_apanel_kernel<T, 128, 3>), dim3(blocks), dim3(256), lds, st, d);
-                } else {
-                    static bool done = false;
-                    if (!done) { if (hipFuncSetAttribute((const void*)gemm_apanel_kernel<T, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return LWDETR_ERR_LAUNCH; done = true; }
-                    hipLaunchKernelGGL((gemm_apanel_kernel<T, 64, 3>), dim3(blocks), dim3(256), lds, st, d);
-                }
-                return lwdetr_check_launch();
-            }
+            // (An A-panel-resident schedule - the whole K panel of 64 / 128 rows in LDS, column tiles streamed past it - was built
+            // and measured in round 2 and removed in round 3: at M = 51200 QKV (N 576, K 192) 51 -> 73 / 106 us, projector 1x1
+            // (N 256, K 768) 60 -> 137 us, value projection (N 768, K 256) 62 -> 93 / 124 us. It cuts what a CU pulls in by 2-3x
+            // and loses anyway: with 66-108 KB of LDS a CU holds one or two workgroups whose column tiles, epilogues and store
+            // latencies run back to back, where the 64 x 64 grid keeps 4-5 independent workgroups per CU in flight.)
             if (small && kb64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3, 64>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             else if (small) {
                 // ring depth of the 64 x 64 kernel trades prefetch distance against workgroups per CU (24 KB of LDS at depth 3:

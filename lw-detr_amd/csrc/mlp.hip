@@ -27,17 +27,7 @@
 #define MLP_WAVES_PER_SIMD 2
 #endif
 
-// Phase timing for kernel tuning (tools/mlp_timing.py builds a private copy with -DLWDETR_MLP_TIMING=1; never in the
-// product library): s_memtime stamps of every wave of workgroup 0 at the phase boundaries.
-#ifdef LWDETR_MLP_TIMING
-__device__ unsigned long long g_mlp_timing[8][16];
-#define TSTAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_mlp_timing[threadIdx.x >> 6][i] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int lwdetr_debug_mlp_timing(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_timing), sizeof(g_mlp_timing)) == hipSuccess ? 0 : 1;
-}
-#else
 #define TSTAMP(i) do {} while (0)
-#endif
 
 namespace {
 
@@ -803,11 +793,13 @@ template <typename T, bool QKV, int TT>
 int launch_mlp_small_tt(const MlpParams& p, hipStream_t st) {
     constexpr int C = 192;
     constexpr size_t lds = 16 * TT * (C + 8) * sizeof(T) + (size_t)NW * 6 * TT * 256 * sizeof(float) + 11 * C * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[16] = {};            // per device (a process may drive several GPUs)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (!attr_done[dev]) {
         if (hipFuncSetAttribute((const void*)mlp_small_kernel<T, QKV, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const long blocks = (p.M + 16 * TT - 1) / (16 * TT);
     ProfScope ps(KID_MLP, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C, (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T), st);
@@ -832,18 +824,17 @@ int launch_mlp_p(const MlpParams& p, hipStream_t st) {
     constexpr int X1_TILES = 7;
     constexpr size_t x1_b = X1LDS ? (size_t)X1_TILES * 16 * TT * (C + 8) * sizeof(T) : 0;
     constexpr size_t lds = (tiles_b + x1_b > xchg_b ? tiles_b + x1_b : xchg_b) + (9 + (X1LDS ? 2 : 0)) * C * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    static int ncu_dev[16] = {};               // per device: attribute set + CU count (0 = not initialised)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (!ncu_dev[dev]) {
+        hipDeviceProp_t prop;
+        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, PROJ, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
-        attr_done = true;
+        ncu_dev[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LWDETR_ERR_LAUNCH;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = ncu_dev[dev];
     MlpParams q = p;
     q.ntiles = (int)((p.M + 16 * TT - 1) / (16 * TT));
     long blocks = q.ntiles < ncu ? q.ntiles : ncu;                       // one workgroup per CU, tiles dealt evenly
@@ -864,18 +855,17 @@ int launch_ffn(const MlpParams& p0, int hid, hipStream_t st, int* splits_out) {
     constexpr int PIECE = 64 * EPC;
     constexpr int W1P = (32 * (C + 2 * EPC) + PIECE - 1) / PIECE * PIECE, W2P = (C * (32 + 2 * EPC) + PIECE - 1) / PIECE * PIECE;
     constexpr size_t lds = 2 * (size_t)(W1P + W2P) * sizeof(T) + 9 * C * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    static int ncu_dev[16] = {};               // per device: attribute set + CU count (0 = not initialised)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (!ncu_dev[dev]) {
+        hipDeviceProp_t prop;
+        if (hipFuncSetAttribute((const void*)mlp_kernel<T, C, TT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
-        attr_done = true;
+        ncu_dev[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LWDETR_ERR_LAUNCH;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = ncu_dev[dev];
     MlpParams q = p0;
     q.ntiles = (int)((p0.M + 16 * TT - 1) / (16 * TT));
     int blocks = (q.ntiles + NW - 1) / NW;

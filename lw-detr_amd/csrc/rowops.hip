@@ -11,8 +11,8 @@ constexpr int LN_MAX_CHUNKS = 16;   // per lane: supports C <= 16 lanes * 16 chu
 // bit-identical to a second launch reading `out` (decoder: norm3 followed by the shared decoder.norm, transformer.py:466-517,
 // :397-400) - one pass over the row instead of two launches.
 template <typename T, int NCH>   // NCH = 16-byte chunks held per lane (register resident row)
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, T* __restrict__ out, long ldo,
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* x, long ldx, const float* __restrict__ gamma,      // x / out: no __restrict__ -
+                                                        const float* __restrict__ beta, T* out, long ldo,         // lwdetr_ffn_finish runs in place (out1 == x)
                                                         long M, int C, float eps, long rows_per_batch,
                                                         long out_batch_rows, long out_row_offset,
                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2,

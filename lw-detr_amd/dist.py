@@ -13,14 +13,18 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, single_node=None):
+def init_from_env(backend=None, single_node=None, force=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank); a no-op returning (0, 1, 0) when WORLD_SIZE is absent or 1.
+    Returns (rank, world_size, local_rank). Without a launcher environment (no RANK) a single process is a no-op returning
+    (0, 1, 0); under a launcher the process group is created even for WORLD_SIZE=1 (``force`` overrides either way), so a
+    one-rank ``torchrun`` exercises the same backend initialisation (RCCL on a GPU box) as an N-rank job.
     ``single_node`` (default: inferred from LOCAL_WORLD_SIZE == WORLD_SIZE) gates the loopback-only RCCL bootstrap."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if force is None:
+        force = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world <= 1 and not force:
         return 0, 1, 0
-    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
@@ -58,9 +62,10 @@ def unpack_detections(packed):
     return packed[..., 0], packed[..., 1].long(), packed[..., 2:6]
 
 
-def all_gather_detections(packed, out=None):
-    """All ranks contribute (b, K, 6) with the SAME b; returns (world*b, K, 6) in rank order (identity for world 1)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def all_gather_detections(packed, out=None, always_collective=False):
+    """All ranks contribute (b, K, 6) with the SAME b; returns (world*b, K, 6) in rank order. A group of one rank returns its
+    input unless ``always_collective`` (tests: the collective itself runs on the backend, e.g. RCCL with one GPU)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not always_collective):
         return packed
     world = dist.get_world_size()
     if out is None:
@@ -125,9 +130,9 @@ def to_evaluator_update(image_ids, scores, labels, boxes):
     return {int(i): {"scores": s, "labels": l, "boxes": b} for i, s, l, b in zip(image_ids.tolist(), scores, labels, boxes)}
 
 
-def gather_for_evaluation(image_ids, scores, labels, boxes):
+def gather_for_evaluation(image_ids, scores, labels, boxes, always_collective=False):
     """Every rank contributes its shard (same b on every rank); returns the whole job's (ids, scores, labels, boxes) on
     rank 0 and None elsewhere. Feed rank 0's result to ``to_evaluator_update`` / ``to_coco_results``."""
-    full = all_gather_detections(pack_detections_with_ids(image_ids, scores, labels, boxes))
+    full = all_gather_detections(pack_detections_with_ids(image_ids, scores, labels, boxes), always_collective=always_collective)
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
     return unpack_detections_with_ids(full) if rank == 0 else None

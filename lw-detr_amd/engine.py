@@ -395,6 +395,7 @@ class ForwardPlan:
         # LWDETR_FFN_FUSED=0 (three launches: linear1 + ReLU, linear2 + residual, LayerNorm chain)
         ffn_fused = K.ffn_fused_supported(d, cfg.dim_feedforward, self.T) and os.environ.get("LWDETR_FFN_FUSED", "1") != "0"
         ffn = None if ffn_fused else z(rq, cfg.dim_feedforward)
+        ffn_scratch = None
         lp3 = M * L * P * 3
         ld_oa = _ceil4(lp3)
         oa = z(rq, ld_oa)
@@ -432,7 +433,9 @@ class ForwardPlan:
                 w1, b1, w2c = pw.custom_multi(lay + ".ffn.packed", lambda lay=lay: K.pack_mlp_weights(
                     pw.sd[lay + ".linear1.weight"], pw.sd[lay + ".linear1.bias"], pw.sd[lay + ".linear2.weight"], None, None,
                     self.T))
-                ops.append(K.FfnOp(self.xdec, w1, b1, w2c, pw.f(lay + ".linear2.bias"), *n3))
+                if ffn_scratch is None:      # one scratch for all layers (they run back to back on the plan's stream)
+                    ffn_scratch = torch.empty(K.ffn_partial_floats(rq, d, cfg.dim_feedforward, self.T), dtype=torch.float32, device=dev)
+                ops.append(K.FfnOp(self.xdec, w1, b1, w2c, pw.f(lay + ".linear2.bias"), *n3, partial=ffn_scratch))
                 continue
             ops.append(GemmOp(self.xdec, pw.w(lay + ".linear1.weight"), rq, cfg.dim_feedforward, d, [
                 seg(ffn, 0, cfg.dim_feedforward, ldo=cfg.dim_feedforward, bias=pw.f(lay + ".linear1.bias"), act=ACT_RELU)]))

@@ -142,19 +142,32 @@ def ffn_fused_supported(C_, hid, dtype) -> bool:
     return C_ in (256, 384) and hid % 64 == 0 and dtype in (torch.float16, torch.bfloat16)
 
 
+def ffn_partial_floats(M, C_, hid, dtype) -> int:
+    """Floats of scratch one FfnOp of this shape needs (splits * M * C)."""
+    splits = _nat.lib().lwdetr_ffn_splits(M, C_, hid, _nat.dtype_code(dtype))
+    return max(splits, 0) * M * C_
+
+
 class FfnOp:
     """Decoder FFN + norm3 (+ decoder.norm): x_out = LN1(x + W2 ReLU(W1 x + b1) + b2), hs = LN2(x_out); two launches
     (lwdetr_ffn_partial, lwdetr_ffn_finish). ``w1, b1, w2c`` from ``pack_mlp_weights(..., ln_w=None, ln_b=None)``."""
 
-    def __init__(self, x, w1, b1, w2c, b2, g1, be1, eps1, out1, g2, be2, eps2, out2, M, C_):
+    def __init__(self, x, w1, b1, w2c, b2, g1, be1, eps1, out1, g2, be2, eps2, out2, M, C_, partial=None):
         hid = w1.shape[0]
         assert all(t.dtype == torch.float32 for t in (b1, b2, g1, be1)) and w1.dtype == x.dtype == w2c.dtype
+        assert g2 is None or (g2.dtype == torch.float32 and be2.dtype == torch.float32)
+        assert w1.is_contiguous() and w2c.is_contiguous()
         code = _nat.dtype_code(x.dtype)
         splits = _nat.lib().lwdetr_ffn_splits(M, C_, hid, code)
         if splits <= 0:
             _nat.check(-splits if splits < 0 else 2, "ffn_splits")
         self.splits = splits
-        self.partial = torch.empty(splits, M, C_, dtype=torch.float32, device=x.device)
+        # the f32 partial slabs (splits x M x C): the decoder layers run back to back on one stream, so a launch plan hands
+        # every layer the same scratch (``partial``, at least splits * M * C floats) instead of one allocation per layer
+        if partial is None:
+            partial = torch.empty(splits * M * C_, dtype=torch.float32, device=x.device)
+        assert partial.dtype == torch.float32 and partial.numel() >= splits * M * C_ and partial.is_contiguous()
+        self.partial = partial
         self.a_part = (_ptr(x), C_, _ptr(w1), _ptr(b1), _ptr(w2c), _ptr(self.partial), M, C_, hid, code)
         self.a_fin = (_ptr(x), C_, _ptr(self.partial), splits, _ptr(b2), _ptr(g1), _ptr(be1), float(eps1), _ptr(out1), C_,
                       _ptr(g2) if g2 is not None else None, _ptr(be2) if g2 is not None else None, float(eps2),

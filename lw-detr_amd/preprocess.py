@@ -64,44 +64,46 @@ class SquareResizeNormalize:
         v = torch.arange(256, dtype=torch.float32).view(1, 256)
         self.lut = v.div(255).sub(m).div(s).contiguous().to(self.device)       # ToTensor, then F.normalize: same f32 ops
         # Resample tables are per AXIS LENGTH (the x table depends on the width only, the y table on the height only):
-        # in_size -> (bounds offset, coef offset, ksize) into one growable device buffer (int32 elements). A COCO-style
-        # evaluation sees a few hundred distinct lengths; the cache is bounded (LRU) and a new length is appended to the
-        # device buffer in place - nothing is re-concatenated or re-uploaded.
+        # in_size -> (bounds offset, coef offset, ksize) into one device buffer (int32 elements). A COCO-style evaluation sees
+        # a few hundred distinct lengths. The buffer is append-only until it is full; then it is STARTED OVER (not LRU: every
+        # entry is dropped) - and grown first when one batch alone needs more than it holds, so any batch fits.
         self._axis = {}
-        self._axis_cap = 1024
         self._table_dev = torch.empty(1 << 20, dtype=torch.int32, device=self.device)
         self._table_len = 0
-        self._gen = 0                       # bumped whenever the buffer is started over (offsets handed out before are void)
-
-    def _axis_table(self, n):
-        ent = self._axis.pop(n, None)
-        if ent is None:
-            bounds, coef = resample_tables(n, self.size)
-            flat = np.concatenate([np.ascontiguousarray(bounds).reshape(-1), np.ascontiguousarray(coef).reshape(-1)])
-            if len(self._axis) >= self._axis_cap or self._table_len + flat.size > self._table_dev.numel():
-                if flat.size > self._table_dev.numel():
-                    self._table_dev = torch.empty(2 * flat.size, dtype=torch.int32, device=self.device)
-                # full: start over (the launches of earlier calls are already ordered before this upload on the stream)
-                self._axis.clear()
-                self._table_len = 0
-                self._gen += 1
-            off = self._table_len
-            self._table_dev[off:off + flat.size].copy_(torch.from_numpy(flat))
-            self._table_len += flat.size
-            ent = (off, off + bounds.size, coef.shape[1])
-        self._axis[n] = ent                                                    # most recently used last
-        return ent
+        self._retired = []                   # replaced buffers: earlier (asynchronous) launches may still read them
 
     def _offsets_batch(self, shapes):
-        """(h, w) per image -> (xbounds, xcoef, xksize, ybounds, ycoef, yksize) offsets, all valid at the same time."""
-        lengths = {n for hw in shapes for n in hw}
-        self._axis_cap = max(self._axis_cap, 2 * len(lengths))
-        for _ in range(3):
-            gen = self._gen
-            offs = [self._axis_table(w) + self._axis_table(h) for h, w in shapes]
-            if self._gen == gen:             # no restart while collecting: every offset of the batch is live
-                return offs
-        raise RuntimeError("resample table cache: batch does not fit")
+        """(h, w) per image -> (xbounds, xcoef, xksize, ybounds, ycoef, yksize) offsets, all valid at the same time. The tables
+        of the batch's new axis lengths are built first and uploaded with ONE copy."""
+        lengths = sorted({n for hw in shapes for n in hw})
+        built = {}
+        for n in lengths:
+            if n not in self._axis:
+                bounds, coef = resample_tables(n, self.size)
+                built[n] = (np.ascontiguousarray(bounds).reshape(-1), np.ascontiguousarray(coef).reshape(-1), coef.shape[1])
+        need = sum(bo.size + co.size for bo, co, _ in built.values())
+        if self._table_len + need > self._table_dev.numel():
+            # full: start over with the tables of THIS batch (earlier launches are ordered before the upload on the stream)
+            for n in lengths:
+                if n not in built:
+                    bounds, coef = resample_tables(n, self.size)
+                    built[n] = (np.ascontiguousarray(bounds).reshape(-1), np.ascontiguousarray(coef).reshape(-1), coef.shape[1])
+            need = sum(bo.size + co.size for bo, co, _ in built.values())
+            if need > self._table_dev.numel():
+                self._retired = [self._table_dev]
+                self._table_dev = torch.empty(2 * need, dtype=torch.int32, device=self.device)
+            self._axis.clear()
+            self._table_len = 0
+        if built:
+            off, chunks = self._table_len, []
+            for n, (bo, co, ks) in built.items():
+                self._axis[n] = (off, off + bo.size, ks)
+                chunks += [bo, co]
+                off += bo.size + co.size
+            flat = torch.from_numpy(np.concatenate(chunks).astype(np.int32, copy=False))
+            self._table_dev[self._table_len:off].copy_(flat)
+            self._table_len = off
+        return [self._axis[w] + self._axis[h] for h, w in shapes]
 
     @torch.no_grad()
     def __call__(self, images):

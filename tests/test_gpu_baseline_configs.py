@@ -92,12 +92,17 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
         top = np.argsort(-s_o)[:100]                           # the oracle's 100 most confident detections of the image
         dist = np.abs(b_o[top][:, None, :] - b_m[None, :, :]).max(-1)
         dist = np.where(l_o[top][:, None] == l_m[None, :], dist, np.inf)
-        j = dist.argmin(1)
-        ok = dist[np.arange(len(top)), j] <= px
+        # several detections of one label can sit within `px` of each other (the same object seen by neighbouring queries): among
+        # the candidates inside the box tolerance the partner is the one with the closest score - taking the nearest box made
+        # the score column jump (0.018 -> 0.082 on medium bf16) on a 0.003 change of one logit while every slot-wise figure stood
+        cand = dist <= px
+        ok = cand.any(1)
+        ds = np.where(cand, np.abs(s_o[top][:, None] - s_m[None, :]), np.inf)
+        j = ds.argmin(1)
         total += len(top)
         found += int(ok.sum())
         if ok.any():
-            dscore = max(dscore, float(np.abs(s_o[top][ok] - s_m[j][ok]).max()))
+            dscore = max(dscore, float(ds[np.arange(len(top)), j][ok].max()))
             iou = box_iou_xyxy(b_o[top][ok], b_m[j][ok])
             ious.append(np.diag(iou))
     ious = np.concatenate(ious) if ious else np.zeros(1)

@@ -1,0 +1,55 @@
+"""GPU: the RCCL path of the multi-GPU plan on the one GPU of the test box ("backend nccl, set_device ordering,
+the loopback bootstrap defaults and all_gather_into_tensor on device tensors have never executed"). One rank is started with the
+driver's launch contract (python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(args, timeout=600):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_rccl_all_gather_of_detections_one_rank():
+    r = _torchrun([os.path.join(ROOT, "tests", "rccl_one_rank_driver.py")])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL-OK")]
+    assert line and "backend=nccl" in line[0], r.stdout[-2000:]
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "rccl_one_rank.log"), "w") as f:
+        f.write(line[0] + "\n" + "\n".join(ln for ln in r.stderr.splitlines() if "lwdetr_amd.dist" in ln) + "\n")
+
+
+def test_bench_under_torchrun_one_rank_initialises_rccl():
+    """bench.py launched the way the driver launches it for N > 1, with N = 1: the process group is created on the nccl backend and
+    the line it prints says so."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "tiny", "--batch", "4", "--res", "256", "--steps", "3", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-latency", "--no-roofline"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"].get("backend") == "nccl", d["config"]
+    with open(os.path.join(ROOT, "gpurun_out", "bench_torchrun_one_rank.json"), "w") as f:
+        f.write(json.dumps(d) + "\n")

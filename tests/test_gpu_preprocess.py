@@ -52,22 +52,30 @@ def test_mixed_size_batch_strided_rows_and_upscaling_bit_exact_vs_oracle():
 
 
 def test_table_cache_is_per_axis_length_and_bounded():
-    """resample tables are cached per axis length (x: width, y: height) in one growable device buffer; a
-    stream of distinct sizes neither re-uploads old tables nor grows without bound, and a wrapped cache stays exact."""
+    """resample tables are cached per axis length (x: width, y: height) in one device buffer that is appended to
+    until it is full and then started over; a stream of distinct sizes neither re-uploads old tables nor grows without bound, a
+    wrapped cache stays exact, and a single batch whose tables exceed the buffer makes it grow instead of failing."""
     rng = np.random.default_rng(5)
     tf = infer_transforms(320, dtype=torch.float32, device=DEV)
-    tf._axis_cap = 8                                   # force the restart path quickly (a call needs 4 lengths)
+    tf._table_dev = torch.empty(12000, dtype=torch.int32, device=DEV)        # small: the stream below wraps several times
     first = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
     ref0, _ = P.preprocess([first], 320, torch.float32)
-    ptr = tf._table_dev.data_ptr()
+    ptr, wraps, last_len = tf._table_dev.data_ptr(), 0, 0
     for k in range(12):
         h, w = 64 + 7 * k, 80 + 5 * k
         im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         out, _ = tf([torch.from_numpy(im).to(DEV), torch.from_numpy(first).to(DEV)])
         ref, _ = P.preprocess([im], 320, torch.float32)
         assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref0[0]), k
-        assert len(tf._axis) <= 8
-    assert tf._table_dev.data_ptr() == ptr             # same device buffer throughout: nothing re-concatenated
+        wraps += tf._table_len < last_len
+        last_len = tf._table_len
+        assert tf._table_len <= tf._table_dev.numel()
+    assert wraps >= 1 and tf._table_dev.data_ptr() == ptr      # started over, same buffer: nothing re-allocated or re-concatenated
+    # one batch with more distinct axis lengths than the buffer holds: the buffer grows, the batch is served, results exact
+    many = [rng.integers(0, 256, (200 + 3 * i, 260 + 5 * i, 3), dtype=np.uint8) for i in range(10)]
+    out, _ = tf([torch.from_numpy(m).to(DEV) for m in many])
+    ref, _ = P.preprocess(many, 320, torch.float32)
+    assert torch.equal(out.cpu(), ref) and tf._table_dev.numel() > 12000
 
 
 def test_feeds_the_model_end_to_end():
