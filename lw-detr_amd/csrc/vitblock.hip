@@ -25,6 +25,7 @@
 // 4 h + e: the host permutes the weight columns accordingly (lwdetr_amd/kernels.py:pack_vit_block).
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 // Phase timing for kernel tuning (tools/vitblock_timing.py builds a private copy with -DLWDETR_VB_TIMING; never in the product
@@ -693,12 +694,16 @@ int launch_vb(const VbParams& p, hipStream_t st) {
     // grid: whole rounds of one workgroup per CU, tokens dealt evenly (every wave at most 32 NH tokens)
     const long per_wg = 4L * 32 * NH;
     const long need = (p.M + per_wg - 1) / per_wg;
-    static const char* env = getenv("LWDETR_VB_GRID");                 // tuning: workgroups (>= need)
-    long grid = (need + s.ncu - 1) / s.ncu * s.ncu;
-    if (env && atol(env) >= need) grid = atol(env);
+    // Full tiles on as few workgroups as the rows need (a tile costs the same matrix time however many of its 32 NH token slots
+    // are filled, so spreading 200 workgroups' rows over 256 buys nothing and takes CUs from whatever runs beside this launch);
+    // LWDETR_VB_GRID=rounds restores whole rounds of one workgroup per CU (round-3 measurements), a number forces the grid.
+    static const char* env = getenv("LWDETR_VB_GRID");
+    long grid = need;
+    if (env && !strcmp(env, "rounds")) grid = (need + s.ncu - 1) / s.ncu * s.ncu;
+    else if (env && atol(env) >= need) grid = atol(env);
     // 8-token units are dealt by floor(): a wave can get one unit more than the average
     while (((p.M / 8 + grid * 4 - 1) / (grid * 4)) * 8 > 32 * NH) ++grid;
-    ProfScope ps(KID_MLP, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C,
+    ProfScope ps(KID_VITBLOCK, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C,
                  (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T) + (p.out2 ? 1.0 : 0.0) * p.M * C * sizeof(T), st);
     hipLaunchKernelGGL((vitblock_kernel<T, C, NH, QKV>), dim3((unsigned)grid), dim3(256), lds, st, p);
     return lwdetr_check_launch();

@@ -5,6 +5,7 @@ The module tree (and therefore the state dict) is the reference's; ``forward`` r
 or without ``liblwdetr_hip.so``, ``forward`` raises.
 """
 import copy
+import os
 
 import torch
 from torch import nn
@@ -13,6 +14,8 @@ from .. import _native
 from ..engine import ForwardPlan, PackedWeights
 from .modules import (MLP, Backbone, Joiner, PositionEmbeddingSine, Transformer, focal_prior_bias)
 from .nested import NestedTensor, nested_tensor_from_tensor_list
+
+_STREAMS = int(os.environ.get("LWDETR_STREAMS", "1"))     # 2: experimental two-chain forward (see LWDETR._forward_two_streams)
 
 
 class LWDETR(nn.Module):
@@ -44,6 +47,7 @@ class LWDETR(nn.Module):
         self._packed = None      # PackedWeights for the current (device, dtype, parameter versions)
         self._plans = {}         # (B, H, W) -> ForwardPlan
         self._tok_tensors = None
+        self._side_stream = None
 
     # ---- cache invalidation: any change of device / dtype / parameter values drops the packed weights
     def invalidate_cache(self):
@@ -84,11 +88,11 @@ class LWDETR(nn.Module):
             self._plans = {}
         return self._packed
 
-    def _plan(self, b, h, w, private=False):
+    def _plan(self, b, h, w, private=False, slot=0):
         """Launch plan for a batch shape. ``private`` plans are not cached: a HIP graph owns its plan's buffers and padding
         state, which eager calls of the same shape must never touch."""
         tok, pw = self._packed_weights()
-        key = (b, h, w)
+        key = (b, h, w, slot)
         if private:
             with torch.cuda.device(tok[0]):
                 return ForwardPlan(pw, b, h, w)
@@ -113,9 +117,39 @@ class LWDETR(nn.Module):
                     samples.mask = None
             x, mask = samples.tensors, samples.mask
         b, _, h, w = x.shape
+        if (_STREAMS == 2 and mask is None and _forced_topk is None and _collect is None and b >= 16 and b % 2 == 0
+                and isinstance(samples, torch.Tensor)):
+            return self._forward_two_streams(x, b, h, w)
         plan = self._plan(b, h, w)
         with torch.cuda.device(plan.dev):
             return plan.run(x, mask, forced_topk=_forced_topk, collect=_collect)
+
+    def _forward_two_streams(self, x, b, h, w):
+        """Experimental (LWDETR_STREAMS=2): the two halves of a dense batch as two launch chains on two streams. Every kernel of
+        the path runs its workgroups in lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b);
+        with a second chain a phase ahead or behind, one half's memory phases and vector-bound attention run beside the other
+        half's matrix phases. Images are independent, the result is the concatenation."""
+        half = b // 2
+        plans = [self._plan(half, h, w, slot=i) for i in (0, 1)]
+        dev = plans[0].dev
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(dev)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                out1 = plans[1].run(x[half:], None)
+            out0 = plans[0].run(x[:half], None)
+            cur.wait_stream(side)
+            cat = lambda a, c: torch.cat([a, c], 0)
+            out = {"pred_logits": cat(out0["pred_logits"], out1["pred_logits"]), "pred_boxes": cat(out0["pred_boxes"], out1["pred_boxes"])}
+            if "aux_outputs" in out0:
+                out["aux_outputs"] = [{k: cat(a[k], c[k]) for k in a} for a, c in zip(out0["aux_outputs"], out1["aux_outputs"])]
+            out["enc_outputs"] = {k: cat(out0["enc_outputs"][k], out1["enc_outputs"][k]) for k in out0["enc_outputs"]}
+            for t in (out1["pred_logits"], out1["pred_boxes"]):
+                t.record_stream(cur)
+            return out
 
     @torch.no_grad()
     def capture(self, images, postprocess=None, target_sizes=None):

@@ -78,6 +78,8 @@ def _oracle_chunk(job):
         sc, lb, bx = (_t.stack([r[k] for r in res_]) for k in ("scores", "labels", "boxes"))
     return {"pred_logits": out["pred_logits"].numpy(), "pred_boxes": out["pred_boxes"].numpy(),
             "enc_logits": out["enc_outputs"]["pred_logits"].numpy(), "enc_boxes": out["enc_outputs"]["pred_boxes"].numpy(),
+            "aux_logits": np.stack([a["pred_logits"].numpy() for a in out["aux_outputs"]], 1),
+            "aux_boxes": np.stack([a["pred_boxes"].numpy() for a in out["aux_outputs"]], 1),
             "topk_idx": out["topk_idx"].numpy(), "enc_class_max": col["enc.class_max"].numpy(), "post_scores": sc.numpy(), "post_labels": lb.numpy(), "post_boxes": bx.numpy()}
 
 
@@ -98,6 +100,35 @@ def oracle_batch(size, batch, res, img_seed, seed=0, chunk=2, forced_topk=None):
         with mp.get_context("spawn").Pool(procs) as pool:
             parts = pool.map(_oracle_chunk, jobs)
     return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+
+
+def oracle_lowp(size, n, res, img_seed, dtype, forced_topk, seed=0, threads=16):
+    """The reference arithmetic IN A 16-BIT DTYPE on the CPU: oracle/lwdetr_torch.py with every parameter
+    and the input cast to ``dtype`` - each torch op then rounds its result to that dtype, as the reference does under
+    ``model.half()`` / bfloat16 - for the first ``n`` images of synth_images(., res, res, img_seed), with the two-stage
+    selection forced. The deformable sampling core runs in float32 on the 16-bit value / location / weight tensors (CPU
+    grid_sample returns NaN in half precision; the reference's own path casts there too, models/transformer.py:356).
+    Returns final + encoder logits / boxes as float32 numpy arrays: their distance to the fp32 oracle is what 16-bit
+    arithmetic itself costs on this network - the yardstick for the HIP path's 16-bit error."""
+    import lwdetr_amd
+    from lwdetr_amd.synth import synth_images, synth_state_dict
+    from oracle import lwdetr_torch as O
+    torch.set_num_threads(threads)
+    cfg = lwdetr_amd.get_args(size)
+    model, _, _ = lwdetr_amd.build_model(cfg)
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in synth_state_dict(model.state_dict(), seed=seed).items()}
+    x = synth_images(n, res, res, seed=img_seed).to(dtype)
+    core = O.msda_core
+    O.msda_core = lambda value, shapes, loc, aw: core(value.float(), shapes, loc.float(), aw.float()).to(value.dtype)
+    try:
+        with torch.no_grad():
+            out = O.forward(sd, cfg, x, forced_topk=torch.from_numpy(np.ascontiguousarray(forced_topk[:n])))
+    finally:
+        O.msda_core = core
+    f = lambda t: t.float().numpy()
+    return {"pred_logits": f(out["pred_logits"]), "pred_boxes": f(out["pred_boxes"]),
+            "enc_logits": f(out["enc_outputs"]["pred_logits"]), "enc_boxes": f(out["enc_outputs"]["pred_boxes"]),
+            "aux_logits": [f(a["pred_logits"]) for a in out["aux_outputs"]], "aux_boxes": [f(a["pred_boxes"]) for a in out["aux_outputs"]]}
 
 
 def box_iou_xyxy(a, b):

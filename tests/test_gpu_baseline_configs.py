@@ -14,8 +14,14 @@ reorders near-ties (any 16-bit implementation does), which says nothing about th
     detections per image that the model reports with the same label and every box coordinate within `px` pixels, and the
     score differences of those.
 
-Every bound is <= 2x the value measured on MI355X (written next to it; each run writes gpurun_out/parity_config_*.json,
-the tracked copy is profiles/parity_config_*.json)."""
+  * the yardstick (round 3): the reference arithmetic itself in the configuration's 16-bit dtype (the CPU oracle with every
+    parameter and activation cast, helpers.oracle_lowp) on the first images of the batch, same forced selection. Its distance
+    to the fp32 oracle is what 16-bit arithmetic costs on this network; the HIP path's error on the SAME images must stay
+    within 1.5x of it (it measures ~0.35x: f32 accumulators, LayerNorm statistics and softmax; fewer rounding points);
+  * the auxiliary (per-decoder-layer) outputs are compared at the full batch as well.
+
+The absolute bounds are <= 2x the value measured on MI355X (written next to them; each run writes
+gpurun_out/parity_config_*.json, the tracked copy is profiles/parity_config_*.json)."""
 import json
 import os
 
@@ -24,7 +30,7 @@ import pytest
 import torch
 
 import lwdetr_amd
-from helpers import ROOT, box_iou_xyxy, oracle_batch
+from helpers import ROOT, box_iou_xyxy, oracle_batch, oracle_lowp
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -109,6 +115,24 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
     m.update({"found": found / total, "score": dscore, "match_px": px,
               "iou_of_found_median": float(np.median(ious)), "iou_of_found_p10": float(np.percentile(ious, 10)),
               "config": {"size": size, "res": res, "batch": batch, "dtype": str(dtype).split(".")[-1]}})
+    # ---- auxiliary outputs (decoder layers 0 .. L-2) at the full batch
+    if out.get("aux_outputs"):
+        al = np.stack([a["pred_logits"].float().cpu().numpy() for a in out["aux_outputs"]], 1)
+        ab = np.stack([a["pred_boxes"].float().cpu().numpy() for a in out["aux_outputs"]], 1)
+        m["aux_logit_max"] = float(np.abs(al - exp["aux_logits"]).max())
+        m["aux_box_max"] = float(np.abs(ab - exp["aux_boxes"]).max())
+    # ---- the yardstick: the reference arithmetic in this dtype (CPU), first n16 images, same forced selection
+    n16 = 2
+    low = oracle_lowp(size, n16, res, 4321, dtype, ours)
+    ref16 = {"logit_max": float(max(np.abs(low["pred_logits"] - exp["pred_logits"][:n16]).max(), np.abs(low["enc_logits"] - exp["enc_logits"][:n16]).max())),
+             "logit_mean": float(np.abs(low["pred_logits"] - exp["pred_logits"][:n16]).mean()),
+             "box_max": float(max(np.abs(low["pred_boxes"] - exp["pred_boxes"][:n16]).max(), np.abs(low["enc_boxes"] - exp["enc_boxes"][:n16]).max())),
+             "box_mean": float(np.abs(low["pred_boxes"] - exp["pred_boxes"][:n16]).mean())}
+    ours16 = {"logit_max": float(max(dl[:n16].max(), del_[:n16].max())), "logit_mean": float(dl[:n16].mean()),
+              "box_max": float(max(db[:n16].max(), deb[:n16].max())), "box_mean": float(db[:n16].mean())}
+    m["ref_16bit_err"] = ref16
+    m["ours_same_images"] = ours16
+    m["ours_over_ref_16bit"] = {k: round(ours16[k] / max(ref16[k], 1e-12), 3) for k in ref16}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"parity_config_{name}.json"), "w") as f:
         json.dump(m, f, indent=1)
@@ -117,3 +141,8 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
     assert m["topk_set_overlap"] > b["overlap"] and m["topk_score_gap"] < b["gap"], m
     assert m["logit_max"] < b["logit_max"] and m["box_max"] < b["box_max"] and m["logit_mean"] < b["logit_mean"], m
     assert m["found"] > b["found"] and m["score"] < b["score"], m
+    # calibrated: no worse than 1.5x what the reference's own arithmetic costs in this dtype, on the same images
+    for k in ("logit_max", "logit_mean", "box_max", "box_mean"):
+        assert ours16[k] <= 1.5 * ref16[k], (k, ours16, ref16)
+    if "aux_logit_max" in m:
+        assert m["aux_logit_max"] < 1.5 * b["logit_max"] and m["aux_box_max"] < 1.5 * b["box_max"], m

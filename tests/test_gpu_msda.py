@@ -177,7 +177,7 @@ def test_backward_matches_reference_autograd_goldens(tag, dtype):
     assert np.abs(ga.cpu().numpy() - ca).max() <= ctol * 50 * max(1.0, float(np.abs(ca).max()))
 
 
-@pytest.mark.parametrize("channels", [30, 32, 64, 71])
+@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025])
 def test_function_gradcheck_double(channels):
     """The reference's own gradient test (models/ops/test.py:89-112): numerical vs analytical gradients of
     MSDeformAttnFunction in double precision, same shapes and channel counts."""
@@ -192,6 +192,35 @@ def test_function_gradcheck_double(channels):
     aw = torch.rand(n, lq, m, l, p, device=DEV) + 1e-5
     aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
     assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2), nondet_tol=1e-12)
+
+
+@pytest.mark.parametrize("channels", [2048, 3096])
+def test_function_gradients_large_channel_counts(channels):
+    """The remaining channel counts of the reference's gradient test (models/ops/test.py:111-112: 1025, 2048, 3096; 1025 goes
+    through gradcheck above). A numerical Jacobian over 2 x 30 x 2 x 3096 value elements is minutes of Python loop, so here the
+    analytical gradients of the HIP backward are compared, in double precision, with autograd through the reference's PyTorch
+    core (the oracle restatement) on the same shapes and seed as the reference's test."""
+    from lwdetr_amd.ops.functions import MSDeformAttnFunction
+    from oracle import lwdetr_torch as O
+    n, m, lq, l, p = 1, 2, 2, 2, 2
+    hw = [(6, 4), (3, 2)]
+    shapes = torch.as_tensor(hw, dtype=torch.long, device=DEV)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    s = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    value = (torch.rand(n, s, m, channels, device=DEV) * 0.01).double().requires_grad_(True)
+    loc = torch.rand(n, lq, m, l, p, 2, device=DEV).double().requires_grad_(True)
+    aw = torch.rand(n, lq, m, l, p, device=DEV) + 1e-5
+    aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, aw, 2)
+    go = torch.rand(out.shape, device=DEV, dtype=torch.float64)
+    gv, gl, ga = torch.autograd.grad(out, (value, loc, aw), go)
+    v2, l2, a2 = (t.detach().cpu().requires_grad_(True) for t in (value, loc, aw))
+    ref = O.msda_core(v2, hw, l2, a2)
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 1e-12
+    rv, rl, ra = torch.autograd.grad(ref, (v2, l2, a2), go.cpu())
+    for g, r in ((gv, rv), (gl, rl), (ga, ra)):
+        assert (g.cpu() - r).abs().max().item() <= 1e-10 * max(1.0, r.abs().max().item())
 
 
 def test_backward_model_shapes_and_module_autograd():

@@ -18,6 +18,8 @@ import sys
 
 def bench_name(k):
     """rocprof kernel symbol -> bench.py / prof.hip kernel class (None = not one of ours)."""
+    if "vitblock_kernel" in k:
+        return "vit_block"
     if "mlp_kernel" in k or "mlp_small_kernel" in k:
         return "mlp_fused"
     if "attn_lds_kernel" in k:
