@@ -15,7 +15,17 @@ from ..engine import ForwardPlan, PackedWeights
 from .modules import (MLP, Backbone, Joiner, PositionEmbeddingSine, Transformer, focal_prior_bias)
 from .nested import NestedTensor, nested_tensor_from_tensor_list
 
-_STREAMS = int(os.environ.get("LWDETR_STREAMS", "1"))     # 2: experimental two-chain forward (see LWDETR._forward_two_streams)
+# Dense batches of >= _TWO_STREAM_MIN_BATCH images run as two launch chains on two streams (LWDETR._forward_two_streams):
+# LWDETR_STREAMS=1 turns that off, =2 applies it from 16 images; set_streams() is the run-time switch (tests).
+_STREAMS = int(os.environ.get("LWDETR_STREAMS", "0"))
+_TWO_STREAM_MIN_BATCH = 32
+
+
+def set_streams(n):
+    """0 = default policy (two chains from _TWO_STREAM_MIN_BATCH images), 1 = always one chain, 2 = two chains from 16 images."""
+    global _STREAMS
+    _STREAMS = int(n)
+
 
 
 class LWDETR(nn.Module):
@@ -117,18 +127,19 @@ class LWDETR(nn.Module):
                     samples.mask = None
             x, mask = samples.tensors, samples.mask
         b, _, h, w = x.shape
-        if (_STREAMS == 2 and mask is None and _forced_topk is None and _collect is None and b >= 16 and b % 2 == 0
-                and isinstance(samples, torch.Tensor)):
+        if (_STREAMS != 1 and mask is None and _forced_topk is None and _collect is None and b % 2 == 0
+                and b >= (16 if _STREAMS == 2 else _TWO_STREAM_MIN_BATCH) and isinstance(samples, torch.Tensor)):
             return self._forward_two_streams(x, b, h, w)
         plan = self._plan(b, h, w)
         with torch.cuda.device(plan.dev):
             return plan.run(x, mask, forced_topk=_forced_topk, collect=_collect)
 
     def _forward_two_streams(self, x, b, h, w):
-        """Experimental (LWDETR_STREAMS=2): the two halves of a dense batch as two launch chains on two streams. Every kernel of
-        the path runs its workgroups in lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b);
-        with a second chain a phase ahead or behind, one half's memory phases and vector-bound attention run beside the other
-        half's matrix phases. Images are independent, the result is the concatenation."""
+        """The two halves of a dense batch as two launch chains on two streams. Every kernel of the path runs its workgroups in
+        lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b); with a second chain a few kernels
+        ahead or behind, one half's bandwidth-bound phases and vector-bound attention run beside the other half's matrix phases
+        (measured: medium B = 64 bf16 6.70 k -> 7.44 k img/s, small B = 32 fp16 11.56 k -> 11.65 k). Images are independent: the
+        result is the concatenation (each half is computed exactly as a batch of b / 2 images is)."""
         half = b // 2
         plans = [self._plan(half, h, w, slot=i) for i in (0, 1)]
         dev = plans[0].dev
@@ -147,8 +158,9 @@ class LWDETR(nn.Module):
             if "aux_outputs" in out0:
                 out["aux_outputs"] = [{k: cat(a[k], c[k]) for k in a} for a, c in zip(out0["aux_outputs"], out1["aux_outputs"])]
             out["enc_outputs"] = {k: cat(out0["enc_outputs"][k], out1["enc_outputs"][k]) for k in out0["enc_outputs"]}
-            for t in (out1["pred_logits"], out1["pred_boxes"]):
-                t.record_stream(cur)
+            for t in [out1["pred_logits"], out1["pred_boxes"]] + list(out1["enc_outputs"].values()) + \
+                    [v for a in out1.get("aux_outputs", []) for v in a.values()]:
+                t.record_stream(cur)            # allocated on the side stream, read by the concatenation on this one
             return out
 
     @torch.no_grad()

@@ -168,8 +168,10 @@ def test_full_size_batch_is_consistent_with_the_golden_validated_small_batch_pat
     big = model(x, _collect=col)
     topk = col["topk_idx"].clone()
     logits, boxes = big["pred_logits"].clone(), big["pred_boxes"].clone()
-    again = model(x)
+    again = model(x, _collect={})                    # the same launch plan (a collecting call runs the batch as one chain)
     assert torch.equal(again["pred_logits"], logits) and torch.equal(again["pred_boxes"], boxes)          # (a)
+    two_a, two_b = model(x), model(x)                # the default two-chain path of a 32-image batch repeats bit for bit as well
+    assert torch.equal(two_a["pred_logits"], two_b["pred_logits"]) and torch.equal(two_a["pred_boxes"], two_b["pred_boxes"])
     small = model(x[:4].contiguous(), _forced_topk=topk[:4])                                               # (b)
     forced = model(x, _forced_topk=topk)
     assert (small["pred_logits"].float() - forced["pred_logits"][:4].float()).abs().max().item() < 0.15
@@ -273,3 +275,34 @@ def test_hip_graph_is_isolated_from_eager_calls_of_the_same_shape():
     eager_dense = model(dense)
     assert torch.equal(eager_dense["pred_logits"], r2["pred_logits"])
     assert (r2["pred_logits"] - p_logits).abs().max().item() > 1e-3                        # padding does change the result
+
+
+def test_two_launch_chains_equal_two_half_batches():
+    """Dense batches of >= 32 images run as two launch chains on two streams (LWDETR._forward_two_streams): the result is, bit for
+    bit, what the model returns for the two half batches one after the other, and within 16-bit noise of the one-chain batch
+    (whose GEMM tiles differ with the row count)."""
+    import lwdetr_amd
+    from lwdetr_amd.models import lwdetr as L
+    from lwdetr_amd.synth import synth_images, synth_state_dict
+    model, _, post = lwdetr_amd.build_model(lwdetr_amd.get_args("small"))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
+    model = model.to("cuda:0").half().eval()
+    x = synth_images(32, 640, 640, seed=11).to("cuda:0").half()
+    try:
+        L.set_streams(0)
+        two = model(x)
+        torch.cuda.synchronize()
+        L.set_streams(1)
+        lo, hi, one = model(x[:16]), model(x[16:]), model(x)
+        torch.cuda.synchronize()
+    finally:
+        L.set_streams(0)
+    for k in ("pred_logits", "pred_boxes"):
+        assert torch.equal(two[k], torch.cat([lo[k], hi[k]], 0)), k
+        assert torch.equal(two["enc_outputs"][k], torch.cat([lo["enc_outputs"][k], hi["enc_outputs"][k]], 0)), k
+    assert len(two["aux_outputs"]) == len(one["aux_outputs"]) and two["aux_outputs"][0]["pred_logits"].shape == one["aux_outputs"][0]["pred_logits"].shape
+    same_sel = (two["enc_outputs"]["pred_boxes"] == one["enc_outputs"]["pred_boxes"]).all(-1).all(-1)        # images whose selection did not reorder
+    assert same_sel.float().mean().item() > 0.5
+    assert (two["pred_logits"][same_sel].float() - one["pred_logits"][same_sel].float()).abs().max().item() < 0.1
+    res = post["bbox"](two, torch.tensor([[480.0, 640.0]] * 32, device="cuda:0"))
+    assert len(res) == 32 and res[31]["boxes"].shape[-1] == 4
