@@ -312,7 +312,7 @@ def main():
 
     if rank == 0 and not a.no_roofline:
         # dedicated pass with per-kernel HIP events on the launch stream (outside the timed region). The timed region runs a
-        # batch of >= 32 images as two launch chains on two streams (LWDETR._forward_two_streams); a kernel's duration measured
+        # batch of >= 32 images as two launch chains on two streams (LWDETR._forward_chains); a kernel's duration measured
         # while the other chain shares the chip says nothing about the kernel, so this pass runs ONE chain: per-kernel figures
         # (and the rocprofv3 summaries under profiles/) are those of the full-batch launches on their own
         from lwdetr_amd.models import lwdetr as _lw

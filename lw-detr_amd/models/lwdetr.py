@@ -15,14 +15,14 @@ from ..engine import ForwardPlan, PackedWeights
 from .modules import (MLP, Backbone, Joiner, PositionEmbeddingSine, Transformer, focal_prior_bias)
 from .nested import NestedTensor, nested_tensor_from_tensor_list
 
-# Dense batches of >= _TWO_STREAM_MIN_BATCH images run as two launch chains on two streams (LWDETR._forward_two_streams):
-# LWDETR_STREAMS=1 turns that off, =2 applies it from 16 images; set_streams() is the run-time switch (tests).
+# Dense batches of >= _TWO_STREAM_MIN_BATCH images run as two launch chains on two streams (LWDETR._forward_chains):
+# LWDETR_STREAMS=1 turns that off, =n runs n chains whenever the parts have >= 8 images; set_streams() is the run-time switch.
 _STREAMS = int(os.environ.get("LWDETR_STREAMS", "0"))
 _TWO_STREAM_MIN_BATCH = 32
 
 
 def set_streams(n):
-    """0 = default policy (two chains from _TWO_STREAM_MIN_BATCH images), 1 = always one chain, 2 = two chains from 16 images."""
+    """0 = default policy (two chains from _TWO_STREAM_MIN_BATCH images), 1 = always one chain, n >= 2 = n chains (parts of >= 8 images)."""
     global _STREAMS
     _STREAMS = int(n)
 
@@ -57,7 +57,7 @@ class LWDETR(nn.Module):
         self._packed = None      # PackedWeights for the current (device, dtype, parameter versions)
         self._plans = {}         # (B, H, W) -> ForwardPlan
         self._tok_tensors = None
-        self._side_stream = None
+        self._side_streams = []
 
     # ---- cache invalidation: any change of device / dtype / parameter values drops the packed weights
     def invalidate_cache(self):
@@ -127,40 +127,55 @@ class LWDETR(nn.Module):
                     samples.mask = None
             x, mask = samples.tensors, samples.mask
         b, _, h, w = x.shape
-        if (_STREAMS != 1 and mask is None and _forced_topk is None and _collect is None and b % 2 == 0
-                and b >= (16 if _STREAMS == 2 else _TWO_STREAM_MIN_BATCH) and isinstance(samples, torch.Tensor)):
-            return self._forward_two_streams(x, b, h, w)
+        nch = self._chains_for(b) if (mask is None and _forced_topk is None and _collect is None and isinstance(samples, torch.Tensor)) else 1
+        if nch > 1:
+            return self._forward_chains(x, b, h, w, nch)
         plan = self._plan(b, h, w)
         with torch.cuda.device(plan.dev):
             return plan.run(x, mask, forced_topk=_forced_topk, collect=_collect)
 
-    def _forward_two_streams(self, x, b, h, w):
-        """The two halves of a dense batch as two launch chains on two streams. Every kernel of the path runs its workgroups in
-        lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b); with a second chain a few kernels
-        ahead or behind, one half's bandwidth-bound phases and vector-bound attention run beside the other half's matrix phases
-        (measured: medium B = 64 bf16 6.70 k -> 7.44 k img/s, small B = 32 fp16 11.56 k -> 11.65 k). Images are independent: the
-        result is the concatenation (each half is computed exactly as a batch of b / 2 images is)."""
-        half = b // 2
-        plans = [self._plan(half, h, w, slot=i) for i in (0, 1)]
+    @staticmethod
+    def _chains_for(b):
+        """Launch chains for a dense batch of b images: default two from _TWO_STREAM_MIN_BATCH images; LWDETR_STREAMS / set_streams:
+        1 = one chain, n >= 2 = n chains whenever the batch splits into n parts of at least 8 images."""
+        if _STREAMS == 1:
+            return 1
+        if _STREAMS >= 2:
+            return _STREAMS if (b % _STREAMS == 0 and b // _STREAMS >= 8) else 1
+        return 2 if (b >= _TWO_STREAM_MIN_BATCH and b % 2 == 0) else 1
+
+    def _forward_chains(self, x, b, h, w, nch):
+        """The parts of a dense batch as ``nch`` launch chains on ``nch`` streams. Every kernel of the path runs its workgroups in
+        lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b); with other chains a few kernels
+        ahead or behind, one part's bandwidth-bound phases and vector-bound attention run beside another part's matrix phases
+        (measured with two chains: medium B = 64 bf16 6.70 k -> 7.34 k img/s, large B = 32 fp16 3.59 k -> 4.06 k, small B = 32
+        fp16 11.66 k -> 11.78 k). Images are independent: the result is the concatenation (each part is computed exactly as
+        a batch of b / nch images is)."""
+        part = b // nch
+        plans = [self._plan(part, h, w, slot=i) for i in range(nch)]
         dev = plans[0].dev
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(dev)
-            side = self._side_stream
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                out1 = plans[1].run(x[half:], None)
-            out0 = plans[0].run(x[:half], None)
-            cur.wait_stream(side)
-            cat = lambda a, c: torch.cat([a, c], 0)
-            out = {"pred_logits": cat(out0["pred_logits"], out1["pred_logits"]), "pred_boxes": cat(out0["pred_boxes"], out1["pred_boxes"])}
-            if "aux_outputs" in out0:
-                out["aux_outputs"] = [{k: cat(a[k], c[k]) for k in a} for a, c in zip(out0["aux_outputs"], out1["aux_outputs"])]
-            out["enc_outputs"] = {k: cat(out0["enc_outputs"][k], out1["enc_outputs"][k]) for k in out0["enc_outputs"]}
-            for t in [out1["pred_logits"], out1["pred_boxes"]] + list(out1["enc_outputs"].values()) + \
-                    [v for a in out1.get("aux_outputs", []) for v in a.values()]:
-                t.record_stream(cur)            # allocated on the side stream, read by the concatenation on this one
+            while len(self._side_streams) < nch - 1:
+                self._side_streams.append(torch.cuda.Stream(dev))
+            outs = [None] * nch
+            for i in range(1, nch):
+                side = self._side_streams[i - 1]
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    outs[i] = plans[i].run(x[i * part:(i + 1) * part], None)
+            outs[0] = plans[0].run(x[:part], None)
+            for i in range(1, nch):
+                cur.wait_stream(self._side_streams[i - 1])
+            cat = lambda ts: torch.cat(ts, 0)
+            out = {"pred_logits": cat([o["pred_logits"] for o in outs]), "pred_boxes": cat([o["pred_boxes"] for o in outs])}
+            if "aux_outputs" in outs[0]:
+                out["aux_outputs"] = [{k: cat([o["aux_outputs"][li][k] for o in outs]) for k in outs[0]["aux_outputs"][li]}
+                                      for li in range(len(outs[0]["aux_outputs"]))]
+            out["enc_outputs"] = {k: cat([o["enc_outputs"][k] for o in outs]) for k in outs[0]["enc_outputs"]}
+            for o in outs[1:]:              # allocated on a side stream, read by the concatenation on this one
+                for t in [o["pred_logits"], o["pred_boxes"]] + list(o["enc_outputs"].values()) + [v for a_ in o.get("aux_outputs", []) for v in a_.values()]:
+                    t.record_stream(cur)
             return out
 
     @torch.no_grad()

@@ -278,7 +278,7 @@ def test_hip_graph_is_isolated_from_eager_calls_of_the_same_shape():
 
 
 def test_two_launch_chains_equal_two_half_batches():
-    """Dense batches of >= 32 images run as two launch chains on two streams (LWDETR._forward_two_streams): the result is, bit for
+    """Dense batches of >= 32 images run as two launch chains on two streams (LWDETR._forward_chains): the result is, bit for
     bit, what the model returns for the two half batches one after the other, and within 16-bit noise of the one-chain batch
     (whose GEMM tiles differ with the row count)."""
     import lwdetr_amd
