@@ -152,7 +152,9 @@ class ForwardPlan:
         self.win_tok = tok_layout(True, self.Hp, self.Wp, self.Twp)
         self.ops_backbone, self.ops_enc, self.ops_sel, self.ops_dec = [], [], [], []
         self.debug = {}
-        self._z = lambda *s, dt=None: torch.zeros(*s, dtype=dt or T, device=dev)
+        self.buffers = []            # every tensor the plan's kernels write (tests/test_gpu_chains.py restores / compares them)
+        self._own = lambda t: (self.buffers.append(t), t)[1]
+        self._z = lambda *s, dt=None: self._own(torch.zeros(*s, dtype=dt or T, device=dev))
         self._build_vit()
         self._build_projector()
         self._build_transformer()
@@ -336,8 +338,8 @@ class ForwardPlan:
         self.shapes_t = torch.tensor(self.level_hw, dtype=torch.int64, device=dev)
         self.lsi_t = torch.tensor(self.lsi, dtype=torch.int64, device=dev)
         # ---- encoder-side (all S tokens): enc_output Linear+LN, class logits; value_proj of all decoder layers
-        self.rowvalid = torch.ones(B * S, dtype=torch.uint8, device=dev)
-        self.notpad = torch.ones(B * S, dtype=torch.uint8, device=dev)
+        self.rowvalid = self._own(torch.ones(B * S, dtype=torch.uint8, device=dev))
+        self.notpad = self._own(torch.ones(B * S, dtype=torch.uint8, device=dev))
         e1, self.om = z(B * S, d), z(B * S, d)
         self.ncls = pw.sd["class_embed.weight"].shape[0]
         self.ldc = _ceil4(self.ncls)
@@ -382,8 +384,8 @@ class ForwardPlan:
         self.xdec = z(rq, d)
         self.sine = z(rq, 2 * d)
         self.qpos = z(rq, d)
-        self.ref = torch.zeros(B, nq, 4, dtype=torch.float32, device=dev)
-        self.vr = torch.ones(B, L, 2, dtype=torch.float32, device=dev)
+        self.ref = self._own(torch.zeros(B, nq, 4, dtype=torch.float32, device=dev))
+        self.vr = self._own(torch.ones(B, L, 2, dtype=torch.float32, device=dev))
         self.hs = z(nl, rq, d)
         r1 = z(rq, d)
         rp = f"{t}.decoder.ref_point_head.layers"
@@ -399,6 +401,7 @@ class ForwardPlan:
         lp3 = M * L * P * 3
         ld_oa = _ceil4(lp3)
         oa = z(rq, ld_oa)
+        self.dec_bufs = dict(xdec=self.xdec, qpos=self.qpos, q=qd, k=kd, vt=vtd, att=attd, y=y, ca=ca, oa=oa, hs=self.hs)   # tools/determinism_probe.py
         for li in range(nl):
             lay = f"{t}.decoder.layers.{li}"
             ipw, ipb = lay + ".self_attn.in_proj_weight", lay + ".self_attn.in_proj_bias"
@@ -459,12 +462,12 @@ class ForwardPlan:
         self.refpoint = pw.f("refpoint_embed.weight", lambda w_: w_[:nq], "g0")
         # ---- fused glue launches (gather of the selected rows, decoder inputs, final boxes)
         code = K._nat.dtype_code(self.T)
-        f32 = lambda *s_: torch.zeros(*s_, dtype=torch.float32, device=dev)
+        f32 = lambda *s_: self._own(torch.zeros(*s_, dtype=torch.float32, device=dev))
         self._pad_state = None
         props0, valid0 = self._proposals(None)
         self._props_static, self._valid_static = props0.contiguous(), valid0.reshape(-1).to(torch.uint8)
         self.props = self._props_static.clone()
-        self.topk_idx = torch.zeros(B, nq, dtype=torch.int64, device=dev)
+        self.topk_idx = self._own(torch.zeros(B, nq, dtype=torch.int64, device=dev))
         self.enc_logits_sel, self.enc_boxes = z(B, nq, self.ncls), z(B, nq, 4)
         self.props_sel = f32(B, nq, 4)
         self.coord = z(nl, B, nq, 4)

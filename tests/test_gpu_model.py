@@ -290,16 +290,20 @@ def test_two_launch_chains_equal_two_half_batches():
     x = synth_images(32, 640, 640, seed=11).to("cuda:0").half()
     try:
         L.set_streams(0)
-        two = model(x)
+        twos = [model(x) for _ in range(24)]          # repeated: kernels of the two chains share CUs in a different way every time
+        two = twos[0]
         torch.cuda.synchronize()
         L.set_streams(1)
         lo, hi, one = model(x[:16]), model(x[16:]), model(x)
         torch.cuda.synchronize()
     finally:
         L.set_streams(0)
-    for k in ("pred_logits", "pred_boxes"):
-        assert torch.equal(two[k], torch.cat([lo[k], hi[k]], 0)), k
-        assert torch.equal(two["enc_outputs"][k], torch.cat([lo["enc_outputs"][k], hi["enc_outputs"][k]], 0)), k
+    for rep, t in enumerate(twos):
+        for k in ("pred_logits", "pred_boxes"):
+            assert torch.equal(t[k], torch.cat([lo[k], hi[k]], 0)), (k, rep)
+            assert torch.equal(t["enc_outputs"][k], torch.cat([lo["enc_outputs"][k], hi["enc_outputs"][k]], 0)), (k, rep)
+            for la, (a, b) in enumerate(zip(lo["aux_outputs"], hi["aux_outputs"])):
+                assert torch.equal(t["aux_outputs"][la][k], torch.cat([a[k], b[k]], 0)), (k, rep, la)
     assert len(two["aux_outputs"]) == len(one["aux_outputs"]) and two["aux_outputs"][0]["pred_logits"].shape == one["aux_outputs"][0]["pred_logits"].shape
     same_sel = (two["enc_outputs"]["pred_boxes"] == one["enc_outputs"]["pred_boxes"]).all(-1).all(-1)        # images whose selection did not reorder
     assert same_sel.float().mean().item() > 0.5
