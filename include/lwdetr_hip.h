@@ -214,9 +214,12 @@ int lwdetr_decoder_inputs(const void* enc_delta, const float* props_sel, const f
 /* out[r] = (delta_xy * ref_wh + ref_xy, exp(delta_wh) * ref_wh) with ref row r % ref_rows (no sigmoid: bbox_reparam). */
 int lwdetr_box_reparam(const void* delta, const float* ref, long ref_rows, void* out, long R, int dtype, void* hip_stream);
 /* lwdetr_box_reparam into coord_out AND logits_out (R, ncls) contiguous = logits_pad (R rows, row stride ldc)[:, :ncls]: the
- * user-visible pred_boxes / pred_logits of all decoder layers (models/lwdetr.py:150-173) in one launch. */
+ * user-visible pred_boxes / pred_logits of all decoder layers (models/lwdetr.py:150-173) in one launch. Input row
+ * layer * ref_rows + k is written to output row layer * out_layer_rows + k (out_layer_rows >= ref_rows; 0 = ref_rows, i.e.
+ * contiguous): a call that owns images [b0, b0 + B) of a (layers, B_total, nq, .) tensor passes the pointers of row b0 * nq and
+ * out_layer_rows = B_total * nq. */
 int lwdetr_finalize_outputs(const void* delta, const float* ref, long ref_rows, void* coord_out, long R, const void* logits_pad,
-                            long ldc, int ncls, void* logits_out, int dtype, void* hip_stream);
+                            long ldc, int ncls, void* logits_out, long out_layer_rows, int dtype, void* hip_stream);
 
 /* ---- sorted top-k (one workgroup per image) and its two users -----------------------------------------------------
  * Order: descending value, equal values by ascending index (torch.topk leaves tie order unspecified). N < 2^20, K <= 1024.

@@ -95,7 +95,7 @@ def lib():
         l.lwdetr_topk.argtypes = [vp, i, i, i, vp, vp, i, vp]
         l.lwdetr_postprocess.argtypes = [vp, vp, vp, i, i, i, i, vp, vp, vp, i, vp]
         l.lwdetr_postprocess_packed.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
-        l.lwdetr_finalize_outputs.argtypes = [vp, vp, lg, vp, lg, vp, lg, i, vp, i, vp]
+        l.lwdetr_finalize_outputs.argtypes = [vp, vp, lg, vp, lg, vp, lg, i, vp, lg, i, vp]
         l.lwdetr_resize_normalize.argtypes = [vp, i, i, vp, vp, vp, vp, i, i, vp]
         l.lwdetr_prof_enable.argtypes = [i]
         l.lwdetr_prof_num_kernels.argtypes = []

@@ -468,6 +468,10 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
 
     int slot = 0;
     for (int kb = 0; kb < nblk; ++kb) {
+        // every K / V^T fragment read of stage kb - 1 has returned before this wave lets the others refill that buffer: hipcc does
+        // not see the DMA and may sink the last MFMAs of a stage (and the lgkmcnt wait of their operands) below the barrier
+        // (the 3x3 convolution kernel was caught by exactly this beside another stream's LDS-heavy kernels, gemm.hip)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         attn_wait_vmcnt<(NST - 2) * PPW>();            // stage kb has landed (this wave's pieces) ...
         __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody has also left stage kb - 1
         {

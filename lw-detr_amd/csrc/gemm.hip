@@ -460,6 +460,14 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];      // zero p
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// one 1 KB DMA piece, untracked by hipcc (inline assembly; drained by counted waits): lane l's 16 bytes land at the wave-uniform
+// LDS address lds_wave_base + 16 l
+__device__ __forceinline__ void gdma16(const void* src, const void* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
+}
+
 // KB = k-depth of a stage: 32 (a DMA piece = 16 rows x 64 B) or 64 (8 rows x 128 B: whole cache lines, half the
 // barriers / waits / address updates per byte; slot c of row r lives at slot c ^ ((r >> 1) & (KB / 8 - 1))).
 template <typename T, int BM, int BN, int AMODE, int NST, int KB = 32>
@@ -611,6 +619,184 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
     gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, smem, m0, n0);
 }
 
+template <typename T> struct Mma32;
+template <> struct Mma32<f16> {
+    static __device__ __forceinline__ f32x16 k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32<bf16> {
+    static __device__ __forceinline__ f32x16 k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+// ---- 3x3 convolution, stride 1, raster (b, y, x) token rows, N = Cin <= 192: the input patch stays in LDS --------------------
+// The implicit-GEMM view above re-fetches every input row nine times (once per tap) and a 128 x 128 tile of it pulls
+// (128 + 128) x 9 Cin x 2 bytes into its CU for 128 x 128 x 9 Cin MACs: at Cin = 128 that is 590 KB per tile in 64-byte segments
+// (27 B / clk / CU, profiles/r2g_ubench_ingress.txt: 9 us of ingress for 3.9 us of MFMA work - the kernel ran at 0.13 of peak).
+// Here a workgroup owns 128 consecutive output pixels and ALL output channels. The pixels' input rows plus W + 1 rows of halo on
+// either side (the taps of pixel m are rows m + dy W + dx of the same image) are DMA'd into LDS once, as whole rows; the
+// fragments of all nine taps are read from that patch at a tap-dependent row offset, and only the weights stream through an
+// NST-deep ring of 32-deep stages: 54 KB + 295 KB of ingress per workgroup instead of 590 KB, in contiguous pieces.
+// Taps that fall outside the image (first / last row or column; a tile may also straddle two images) are masked in the fragment:
+// per lane a 9-bit validity word per 32-row tile, and a wave-uniform "some lane needs it" word so that interior tiles pay nothing.
+// 32x32x16 MFMAs (D[n][m] = W fragment x pixel fragment, as in gemm_big_kernel): the 16 lanes a ds_read_b128 serves together then
+// hold the SAME k-run of 16 different rows, whatever the tap's row offset, and patch rows padded by one 16-byte slot (row stride
+// 17 / 25 slots: odd) put those rows on 16 different banks; a chunk's offset inside the row stays an immediate. (With the
+// 16x16x32 layout a service group mixes two k-runs and no row-major image is conflict-free for odd AND even row offsets.)
+template <typename T, int CIN, int BN, int NST>
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_desc d, int np_patch) {
+    constexpr int BM = 128, KB = 32, EPC = 8;
+    constexpr int SPR = CIN / EPC + 1, RS = SPR * EPC;      // slots / elements per patch row (one pad slot)
+    constexpr int NCH = CIN / KB;                           // stages per tap
+    constexpr int B_MY = BN / 16 / 4;                       // weight pieces (16 rows x 64 B) per wave and stage
+    constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
+    typedef typename Vec<T>::v8 V8;
+    static_assert(sizeof(T) == 2 && BN % 64 == 0 && CIN % KB == 0, "16-bit, whole pieces");
+    extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
+    T* patch = (T*)conv_smem;
+    T* ring = patch + (long)np_patch * 512;                 // np_patch pieces of 1 KB
+
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;      // neighbouring tiles (shared halo) on one XCD
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const long m0 = (long)wg * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Wimg = d.conv_wout, Himg = d.conv_hout, PR = BM + 2 * Wimg + 2;
+    const T* __restrict__ A = (const T*)d.A + d.a_col0;
+    const T* __restrict__ W = (const T*)d.W;
+    const T* zero = (const T*)g_zero16;
+
+    // ---- weight ring: stage image of gemm_big_kernel at KB = 32 (16-byte slot c of row r at slot c ^ ((r >> 2) & 3))
+    const int prow = lane >> 2, pslot = lane & 3;
+    const T* w_src[B_MY];
+#pragma unroll
+    for (int k = 0; k < B_MY; ++k) {
+        const int n = 16 * (wave + 4 * k) + prow;
+        w_src[k] = n < d.N ? W + (long)n * d.K + (pslot ^ ((prow >> 2) & 3)) * EPC : nullptr;
+    }
+    const int nk = 9 * NCH;
+    auto stage = [&](int kt, int slot) {
+        T* Bs = ring + slot * (BN * KB);
+#pragma unroll
+        for (int k = 0; k < B_MY; ++k) gdma16((kt < nk && w_src[k]) ? w_src[k] + kt * KB : zero, Bs + (wave + 4 * k) * 64 * EPC);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) stage(s, s);
+    // ---- the patch: piece p = 64 consecutive 16-byte slots of the padded row image
+    for (int p = wave; p < np_patch; p += 4) {
+        const int q = p * 64 + lane, pr = q / SPR, ps = q - pr * SPR;
+        const long gm = m0 - Wimg - 1 + pr;
+        const bool ok = ps < SPR - 1 && pr < PR && gm >= 0 && gm < d.M;
+        gdma16(ok ? A + gm * d.lda + ps * EPC : zero, patch + (long)p * 512);
+    }
+
+    // ---- validity of the nine taps for this lane's two pixels; wave-uniform "some lane needs the mask" words
+    unsigned vbits[TM], need[TM];
+    {
+        const int hw = Himg * Wimg;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long m = m0 + wm * 64 + i * 32 + l31;
+            const int r = (int)(m % hw), y = r / Wimg, x = r - y * Wimg;
+            unsigned v = 0, nd = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                const bool ok = iy >= 0 && iy < Himg && ix >= 0 && ix < Wimg;
+                v |= ok ? 1u << tap : 0u;
+                nd |= __builtin_amdgcn_ballot_w64(!ok) != 0 ? 1u << tap : 0u;
+            }
+            vbits[i] = v; need[i] = __builtin_amdgcn_readfirstlane(nd);
+        }
+    }
+    const T* a_base[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_base[i] = patch + (wm * 64 + i * 32 + l31) * RS + h * EPC;
+    int wrow[TN], wsw[TN];                                   // this lane's weight row inside a stage and its swizzle key
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { wrow[j] = (wn * WN + j * 32 + l31) * KB; wsw[j] = (l31 >> 2) & 3; }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+    wait_vmcnt<0>();
+    int kt = 0, slot = 0;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int toff = (Wimg + 1 + (tap / 3 - 1) * Wimg + (tap % 3 - 1)) * RS;
+        unsigned keep[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) keep[i] = (vbits[i] >> tap) & 1 ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // every fragment read of stage kt - 1 has RETURNED before this wave lets the others refill that buffer: the DMA is
+            // invisible to hipcc, which is free to sink the MFMAs of the previous stage - and with them the lgkmcnt wait of their
+            // operands - below the barrier (seen beside LDS-heavy kernels of another stream: reads queued behind the
+            // neighbours' LDS traffic were overtaken by the refill; tools/conv_stress.py)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_vmcnt<(NST - 2) * B_MY>();                   // stage kt has landed (this wave's pieces) ...
+            __builtin_amdgcn_s_barrier();                     // ... and everybody's (first pass: the patch too); stage kt - 1 is free
+            {
+                int ns = slot + NST - 1; ns = ns >= NST ? ns - NST : ns;
+                stage(kt + NST - 1, ns);
+            }
+            const T* Bs = ring + slot * (BN * KB);
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {                  // two 16-deep MFMA steps per stage
+                V8 xf[TM], wf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wf[j] = *(const V8*)(Bs + wrow[j] + ((2 * kc + h) ^ wsw[j]) * EPC);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    xf[i] = *(const V8*)(a_base[i] + toff + c * KB + kc * 16);
+                    if ((need[i] >> tap) & 1) {
+                        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                        u32x4v u = __builtin_bit_cast(u32x4v, xf[i]);
+                        u = u & keep[i];
+                        xf[i] = __builtin_bit_cast(V8, u);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[j][i] = Mma32<T>::k16(wf[j], xf[i], acc[j][i]);
+            }
+            ++kt; slot = slot + 1 == NST ? 0 : slot + 1;
+        }
+    }
+    wait_vmcnt<0>();            // the dummy tail pieces
+    __syncthreads();            // ... and everybody's last fragment reads, before the patch becomes the epilogue's staging area
+    // ---- epilogue: 64 rows per pass through the f32 stage area (aliases the patch), finished by all 256 threads.
+    // 32x32 accumulator: register 4 q + r of lane (c = lane & 31, hi) is element (row 8 q + 4 hi + r, column c) of D = W x pixels.
+    float* stg = (float*)conv_smem;
+    constexpr int SLD = BN + 4;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]};
+                        *(f32x4*)(stg + (i * 32 + l31) * SLD + wn * WN + j * 32 + q * 8 + h * 4) = v;
+                    }
+        }
+        __syncthreads();
+        epilogue_finish<T, BN, 256>(d, d.seg[0], false, stg, m0 + pass * 64, 0);
+        __syncthreads();
+    }
+}
+
 // ---- A-panel-resident variant (16-bit, plain A, K <= 768): one workgroup owns BM rows and ALL N columns. The BM x K panel
 // of A is DMA'd into LDS once and stays; the weight matrix streams through an NST-deep ring of 64 x 64 stages while the
 // workgroup walks the column tiles. Why: these GEMMs have short K and are bound by what a CU can pull in per output tile -
@@ -620,11 +806,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
 // The DMA goes through inline assembly (untracked by hipcc, see mlp.hip) and is drained by counted waits; the epilogue's
 // global stores share vmcnt with it and loads / stores may retire out of order, so the first wait after an epilogue drains
 // the counter completely (the ring pieces in flight have had the whole epilogue to land).
-__device__ __forceinline__ void gdma16(const void* src, const void* lds_wave_base) {
-    const unsigned m0v = __builtin_amdgcn_readfirstlane(
-        (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(src) : "memory");
-}
 
 
 
@@ -652,14 +833,6 @@ extern "C" int lwdetr_debug_big_timing(unsigned long long* out) {
 }
 #define BIG_NOW() __builtin_amdgcn_s_memrealtime()
 #endif
-template <typename T> struct Mma32;
-template <> struct Mma32<f16> {
-    static __device__ __forceinline__ f32x16 k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mma32<bf16> {
-    static __device__ __forceinline__ f32x16 k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
-
 template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d) {
     static_assert(sizeof(T) == 2, "16-bit types only");
@@ -974,6 +1147,53 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
     }
 }
 
+// The patch-resident 3x3 convolution takes: stride 1, raster token rows in and out (the C2f bottleneck convolutions of the
+// projector), one LINEAR segment, N = Cin in {128, 192}, and a patch (128 + 2 W + 2 rows) that fits beside the weight ring in
+// 160 KB. LWDETR_CONV_PATCH: 0 = off, 1 = default, 2 = every legal shape (tuning / A-B runs / tests).
+template <typename T, int CIN, int NST>
+int launch_conv_patch(const lwdetr_gemm_desc& d, hipStream_t st) {
+    constexpr int SPR = CIN / 8 + 1;
+    const int pr = 128 + 2 * d.conv_wout + 2;
+    const int np = (pr * SPR + 63) / 64;
+    size_t lds = (size_t)np * 1024 + (size_t)NST * CIN * 32 * sizeof(T);
+    const size_t stg = (size_t)64 * (CIN + 4) * sizeof(float);
+    if (lds < stg) lds = stg;
+    if (lds > 160 * 1024) return LWDETR_ERR_UNSUPPORTED;
+    static signed char state[16] = {};          // per device: 0 = not asked yet, 1 = granted, -1 = refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_UNSUPPORTED;
+    if (state[dev] == 0)
+        state[dev] = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, CIN, CIN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : -1;
+    if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
+    const long nwg = (d.M + 127) / 128;
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, CIN, NST>), dim3((unsigned)nwg), dim3(256), lds, st, d, np);
+    return lwdetr_check_launch();
+}
+
+template <typename T>
+int try_launch_conv_patch(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
+    taken = false;
+    if constexpr (sizeof(T) != 2) return LWDETR_OK;
+    else {
+        const char* env = getenv("LWDETR_CONV_PATCH");       // read per launch: tests switch it inside one process
+        const int mode = env ? atoi(env) : 1;                // 0 = never, 1 = default (N = 128), 2 = whenever legal
+        if (mode == 0) return LWDETR_OK;
+        // N = Cin = 192 (the C = 384 models: 117-153 KB of LDS, one workgroup per CU) measured SLOWER than the 256-row large-tile
+        // kernel with its 192-wide column tile (large, B = 32: 16 launches 2.24 vs 1.93 ms per step) - off unless asked for
+        if (mode == 1 && d.N != 128) return LWDETR_OK;
+        const lwdetr_gemm_seg& g = d.seg[0];
+        const long hw = (long)d.conv_hout * d.conv_wout;
+        if (d.conv_stride != 1 || d.a_tok.winmajor || d.a_tok.Hp != d.conv_hout || d.a_tok.Wp != d.conv_wout || d.nseg != 1 ||
+            g.mode != LWDETR_OUT_LINEAR || d.N != d.conv_cin || d.K != 9 * d.conv_cin || (d.N != 128 && d.N != 192) ||
+            d.lda % 8 != 0 || d.a_col0 % 8 != 0 || ((size_t)d.A & 15) != 0 || ((size_t)d.W & 15) != 0 || hw <= 0 || d.M % hw != 0 ||
+            d.M / 128 > 0x7ffffff0L)
+            return LWDETR_OK;
+        const int rc = d.N == 128 ? launch_conv_patch<T, 128, 3>(d, st) : launch_conv_patch<T, 192, 3>(d, st);
+        taken = rc != LWDETR_ERR_UNSUPPORTED;
+        return taken ? rc : LWDETR_OK;
+    }
+}
+
 template <typename T, int AMODE>
 int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     // column tile: 128 unless a segment boundary (or a small N) asks for 64
@@ -1003,6 +1223,11 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     if (nwg <= 0 || nwg > 0x7fffffffL) return LWDETR_ERR_BAD_ARG;
     const int kid = AMODE == LWDETR_A_PLAIN ? KID_GEMM : (AMODE == LWDETR_A_CONV3x3 ? KID_GEMM_CONV : KID_GEMM_PATCH);
     ProfScope ps(kid, 2.0 * d.M * d.N * d.K, ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) * sizeof(T), st);
+    if constexpr (AMODE == LWDETR_A_CONV3x3) {
+        bool taken = false;
+        const int rc = try_launch_conv_patch<T>(d, st, taken);
+        if (taken) return rc;
+    }
     {
         bool taken = false;
         const int rc = try_launch_big<T, AMODE>(d, st, taken);

@@ -261,23 +261,28 @@ __global__ __launch_bounds__(256) void box_reparam_kernel(const T* __restrict__ 
 }
 
 // final boxes of all decoder layers (box_reparam) AND the contiguous copy of their class logits out of the padded GEMM
-// output, in one launch: element i of the R x ncls logits block is copied by thread i, threads i < R also do row i's box
+// output, in one launch: element i of the R x ncls logits block is copied by thread i, threads i < R also do row i's box.
+// Input row r = layer * ref_rows + k lands in output row layer * out_layer_rows + k: with out_layer_rows > ref_rows the call
+// fills its images' rows of a (layers, B_total, nq, .) tensor that other launch chains fill the rest of.
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_outputs_kernel(const T* __restrict__ delta, const float* __restrict__ ref, long ref_rows,
                                                                T* __restrict__ coord, long R, const T* __restrict__ logits_pad,
-                                                               long ldc, int ncls, T* __restrict__ logits_out) {
+                                                               long ldc, int ncls, T* __restrict__ logits_out, long layer_gap) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < R * ncls) {
         const long r = i / ncls;
-        logits_out[i] = logits_pad[r * ldc + (i - r * ncls)];
+        const long orow = r + (r / ref_rows) * layer_gap;
+        logits_out[orow * ncls + (i - r * ncls)] = logits_pad[r * ldc + (i - r * ncls)];
     }
     if (i < R) {
-        const float* rf = ref + (i % ref_rows) * 4;
+        const long k = i % ref_rows;
+        const float* rf = ref + k * 4;
+        T* o = coord + (i + (i / ref_rows) * layer_gap) * 4;
         const float d0 = to_f32<T>(delta[i * 4]), d1 = to_f32<T>(delta[i * 4 + 1]), d2 = to_f32<T>(delta[i * 4 + 2]), d3 = to_f32<T>(delta[i * 4 + 3]);
-        coord[i * 4] = from_f32<T>(d0 * rf[2] + rf[0]);
-        coord[i * 4 + 1] = from_f32<T>(d1 * rf[3] + rf[1]);
-        coord[i * 4 + 2] = from_f32<T>(expf(d2) * rf[2]);
-        coord[i * 4 + 3] = from_f32<T>(expf(d3) * rf[3]);
+        o[0] = from_f32<T>(d0 * rf[2] + rf[0]);
+        o[1] = from_f32<T>(d1 * rf[3] + rf[1]);
+        o[2] = from_f32<T>(expf(d2) * rf[2]);
+        o[3] = from_f32<T>(expf(d3) * rf[3]);
     }
 }
 
@@ -327,14 +332,17 @@ extern "C" int lwdetr_box_reparam(const void* delta, const float* ref, long ref_
 }
 
 extern "C" int lwdetr_finalize_outputs(const void* delta, const float* ref, long ref_rows, void* coord_out, long R,
-                                       const void* logits_pad, long ldc, int ncls, void* logits_out, int dtype, void* hip_stream) {
+                                       const void* logits_pad, long ldc, int ncls, void* logits_out, long out_layer_rows, int dtype,
+                                       void* hip_stream) {
     if (!delta || !ref || !coord_out || !logits_pad || !logits_out || R < 0 || ref_rows <= 0 || ncls <= 0 || ldc < ncls) return LWDETR_ERR_BAD_ARG;
+    if (out_layer_rows == 0) out_layer_rows = ref_rows;
+    if (out_layer_rows < ref_rows) return LWDETR_ERR_BAD_ARG;
     if (R == 0) return LWDETR_OK;
     hipStream_t st = (hipStream_t)hip_stream;
     ProfScope ps(KID_ELTWISE, 0.0, 0.0, st);
     const long n = R * ncls;
     LWDETR_DISPATCH_T(dtype, hipLaunchKernelGGL((finalize_outputs_kernel<TT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                                 (const TT*)delta, ref, ref_rows, (TT*)coord_out, R, (const TT*)logits_pad, ldc, ncls,
-                                                (TT*)logits_out));
+                                                (TT*)logits_out, out_layer_rows - ref_rows));
     return lwdetr_check_launch();
 }

@@ -485,7 +485,7 @@ class ForwardPlan:
             ptr(self.dim_t), ptr(self.enc_boxes), ptr(self.ref), ptr(self.sine), ptr(self.xdec), B, nq, d, code), keep=())
         self.op_finalize = K.RawOp("lwdetr_finalize_outputs", (
             ptr(self.delta), ptr(self.ref), B * nq, ptr(self.coord), nl * B * nq, ptr(self.logits), self.ldc, self.ncls,
-            ptr(self.logits), code), keep=())        # args 3 (boxes) and 8 (logits) are replaced by the call's output tensors
+            ptr(self.logits), 0, code), keep=())     # args 3 (boxes), 8 (logits), 9 (rows per layer there): the call's output tensors
 
     # ------------------------------------------------------------------------------- per-call host-side glue
     def _masks(self, mask):
@@ -542,8 +542,10 @@ class ForwardPlan:
         self._pad_state = "pad"
 
     @torch.no_grad()
-    def run(self, images, mask=None, forced_topk=None, collect=None):
-        """images (B,3,H,W) on the plan's device; mask (B,H,W) bool or None (= no padding)."""
+    def run(self, images, mask=None, forced_topk=None, collect=None, into=None):
+        """images (B,3,H,W) on the plan's device; mask (B,H,W) bool or None (= no padding). ``into`` = (outputs, b0): write this
+        batch's results into images [b0, b0 + B) of preallocated full-batch tensors (``alloc_outputs``) instead of fresh ones -
+        the launch chains of ``LWDETR._forward_chains`` fill one set of output tensors, no concatenation afterwards."""
         B, S, d, nq, T = self.B, self.S, self.d, self.nq, self.T
         stream = K._nat.stream_ptr(self.dev)
         if images.dtype == T and images.is_contiguous() and images.device == self.x.device:
@@ -569,26 +571,41 @@ class ForwardPlan:
         # slice-copy launches): encoder logits by the gather, encoder boxes by the decoder-input kernel, the decoder layers'
         # boxes and the contiguous copy of their class logits (the GEMM output rows are padded to ldc) by one final launch
         nl, ncls = self.cfg.dec_layers, self.ncls
-        empty = lambda *sh: torch.empty(*sh, dtype=T, device=self.dev)
-        enc_logits, enc_boxes = empty(B, nq, ncls), empty(B, nq, 4)
-        cls, coord = empty(nl, B, nq, ncls), empty(nl, B, nq, 4)
-        self.op_gather.call_with(stream, {6: enc_logits.data_ptr()})
+        if into is None:
+            (enc_logits, enc_boxes, cls, coord), b0 = self.alloc_outputs(B), 0
+        else:
+            (enc_logits, enc_boxes, cls, coord), b0 = into
+        total, isz = cls.shape[1], cls.element_size()
+        self.op_gather.call_with(stream, {6: enc_logits.data_ptr() + b0 * nq * ncls * isz})
         for op in self.ops_sel:
             op(stream)
-        self.op_dec_inputs.call_with(stream, {7: enc_boxes.data_ptr()})
+        self.op_dec_inputs.call_with(stream, {7: enc_boxes.data_ptr() + b0 * nq * 4 * isz})
         for op in self.ops_dec:
             op(stream)
-        self.op_finalize.call_with(stream, {3: coord.data_ptr(), 8: cls.data_ptr()})
-        out = {"pred_logits": cls[-1], "pred_boxes": coord[-1]}
-        if self.cfg.aux_loss:
-            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(cls[:-1], coord[:-1])]
-        out["enc_outputs"] = {"pred_logits": enc_logits, "pred_boxes": enc_boxes}
+        self.op_finalize.call_with(stream, {3: coord.data_ptr() + b0 * nq * 4 * isz, 8: cls.data_ptr() + b0 * nq * ncls * isz,
+                                            9: total * nq})
+        if into is not None:
+            return None
+        out = self.output_dict(enc_logits, enc_boxes, cls, coord)
         if collect is not None:
             if forced_topk is not None:
                 self.op_rowmax(stream)
             collect.update({"topk_idx": self.topk_idx.clone(), "enc.class_max": self.cls_max.clone(), "memory": self.memory.view(B, S, d).clone(),
                             "taps_cat": self.taps_cat.clone(), "x": self.x.clone(), "hs": self.hs.clone(),
                             "om": self.om.view(B, S, d).clone()})
+        return out
+
+    def alloc_outputs(self, total):
+        """Fresh user-visible tensors for ``total`` images: encoder logits / boxes, all decoder layers' logits / boxes."""
+        nl, nq, ncls = self.cfg.dec_layers, self.nq, self.ncls
+        empty = lambda *sh: torch.empty(*sh, dtype=self.T, device=self.dev)
+        return empty(total, nq, ncls), empty(total, nq, 4), empty(nl, total, nq, ncls), empty(nl, total, nq, 4)
+
+    def output_dict(self, enc_logits, enc_boxes, cls, coord):
+        out = {"pred_logits": cls[-1], "pred_boxes": coord[-1]}
+        if self.cfg.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(cls[:-1], coord[:-1])]
+        out["enc_outputs"] = {"pred_logits": enc_logits, "pred_boxes": enc_boxes}
         return out
 
 

@@ -149,8 +149,8 @@ class LWDETR(nn.Module):
         lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b); with other chains a few kernels
         ahead or behind, one part's bandwidth-bound phases and vector-bound attention run beside another part's matrix phases
         (measured with two chains: medium B = 64 bf16 6.70 k -> 7.34 k img/s, large B = 32 fp16 3.59 k -> 4.06 k, small B = 32
-        fp16 11.66 k -> 11.78 k). Images are independent: the result is the concatenation (each part is computed exactly as
-        a batch of b / nch images is)."""
+        fp16 11.66 k -> 11.78 k). Images are independent: each part is computed exactly as a batch of b / nch images is, and
+        writes its rows of the call's output tensors (allocated on the current stream, which waits for every chain)."""
         part = b // nch
         plans = [self._plan(part, h, w, slot=i) for i in range(nch)]
         dev = plans[0].dev
@@ -158,25 +158,16 @@ class LWDETR(nn.Module):
             cur = torch.cuda.current_stream(dev)
             while len(self._side_streams) < nch - 1:
                 self._side_streams.append(torch.cuda.Stream(dev))
-            outs = [None] * nch
+            outs = plans[0].alloc_outputs(b)        # every chain writes its images' rows of ONE set of output tensors
             for i in range(1, nch):
                 side = self._side_streams[i - 1]
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    outs[i] = plans[i].run(x[i * part:(i + 1) * part], None)
-            outs[0] = plans[0].run(x[:part], None)
+                    plans[i].run(x[i * part:(i + 1) * part], None, into=(outs, i * part))
+            plans[0].run(x[:part], None, into=(outs, 0))
             for i in range(1, nch):
                 cur.wait_stream(self._side_streams[i - 1])
-            cat = lambda ts: torch.cat(ts, 0)
-            out = {"pred_logits": cat([o["pred_logits"] for o in outs]), "pred_boxes": cat([o["pred_boxes"] for o in outs])}
-            if "aux_outputs" in outs[0]:
-                out["aux_outputs"] = [{k: cat([o["aux_outputs"][li][k] for o in outs]) for k in outs[0]["aux_outputs"][li]}
-                                      for li in range(len(outs[0]["aux_outputs"]))]
-            out["enc_outputs"] = {k: cat([o["enc_outputs"][k] for o in outs]) for k in outs[0]["enc_outputs"]}
-            for o in outs[1:]:              # allocated on a side stream, read by the concatenation on this one
-                for t in [o["pred_logits"], o["pred_boxes"]] + list(o["enc_outputs"].values()) + [v for a_ in o.get("aux_outputs", []) for v in a_.values()]:
-                    t.record_stream(cur)
-            return out
+            return plans[0].output_dict(*outs)
 
     @torch.no_grad()
     def capture(self, images, postprocess=None, target_sizes=None):

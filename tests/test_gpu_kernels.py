@@ -153,6 +153,34 @@ def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, big_gemm):
     assert _relerr(out, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("b,hp,wp,c", [(2, 40, 40, 128), (3, 10, 13, 128), (2, 20, 20, 192), (1, 80, 80, 192), (5, 7, 9, 192), (1, 60, 60, 128)])
+def test_gemm_conv3x3_patch_resident(dtype, b, hp, wp, c, monkeypatch):
+    """The patch-resident 3x3 convolution (stride 1, raster rows, N = Cin: the C2f bottleneck convolutions) vs F.conv2d in fp64
+    and vs the implicit-GEMM ring kernel it replaces: image borders, 128-pixel tiles that straddle images (10 x 13, 7 x 9), a
+    ragged last tile, a channel window inside wider rows on both sides (the C2f concat buffer), the widest patch that fits."""
+    from lwdetr_amd import kernels as K
+    ctot, col0, ocol = 5 * c, 2 * c, 3 * c
+    x = _rand(b, hp, wp, ctot, dtype=dtype, seed=1)
+    w = _rand(c, c, 3, 3, dtype=dtype, scale=(9 * c) ** -0.5, seed=2)
+    bias = _rand(c, seed=3)
+    outs = []
+    for patch in ("2", "0"):
+        monkeypatch.setenv("LWDETR_CONV_PATCH", patch)
+        out = torch.full((b * hp * wp, ctot), 3.0, dtype=dtype, device=_dev())
+        K.GemmOp(x.reshape(-1, ctot), w.permute(0, 2, 3, 1).reshape(c, -1).contiguous(), b * hp * wp, c, 9 * c,
+                 [K.seg(out[:, ocol:], 0, c, ldo=ctot, bias=bias, act=K.ACT_SILU)], lda=ctot, a_mode=K.A_CONV3x3,
+                 a_tok=K.tok_layout(False, hp, wp, 0), conv_cin=c, conv_stride=1, a_col0=col0, conv_hout=hp, conv_wout=wp,
+                 keep=(out,))()
+        torch.cuda.synchronize()
+        assert bool((out[:, :ocol] == 3.0).all()) and bool((out[:, ocol + c:] == 3.0).all())        # nothing outside the segment
+        outs.append(out[:, ocol:ocol + c].clone())
+    xin = x[..., col0:col0 + c].double().permute(0, 3, 1, 2)
+    ref = F.silu(F.conv2d(xin, w.double(), bias.double(), padding=1)).permute(0, 2, 3, 1).reshape(-1, c)
+    e_new, e_old = _relerr(outs[0], ref.float()), _relerr(outs[1], ref.float())
+    assert e_new < TOL[dtype] and e_new < 1.5 * e_old + 1e-4, (e_new, e_old)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_deconv2x2_and_tokmap(dtype):
     from lwdetr_amd import kernels as K
