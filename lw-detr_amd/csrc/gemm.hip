@@ -641,18 +641,46 @@ template <> struct Mma32<bf16> {
 // hold the SAME k-run of 16 different rows, whatever the tap's row offset, and patch rows padded by one 16-byte slot (row stride
 // 17 / 25 slots: odd) put those rows on 16 different banks; a chunk's offset inside the row stays an immediate. (With the
 // 16x16x32 layout a service group mixes two k-runs and no row-major image is conflict-free for odd AND even row offsets.)
+// Phase timing (tools/conv_ablate.sh timing: -DLWDETR_CONV_TIMING=<workgroup>, never in the product): per wave of that workgroup,
+// 10 ns ticks at: patch + first stages issued, masks computed, everything landed, loop done (with the time spent in the lgkmcnt
+// wait, the vmcnt wait and the barrier inside it), epilogue done.
+#ifdef LWDETR_CONV_TIMING
+__device__ unsigned long long g_conv_timing[4][12];
+extern "C" int lwdetr_debug_conv_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_timing), sizeof(g_conv_timing)) == hipSuccess ? 0 : -1;
+}
+#define CONV_NOW() __builtin_amdgcn_s_memrealtime()
+#endif
+// Tuning builds (tools/conv_ablate.sh, -DLWDETR_CONV_ABL=bits, wrong results): 1 = no MFMAs, 2 = no patch DMA, 4 = no epilogue,
+// 8 = no weight DMA, 16 = no fragment reads, 32 = no lgkmcnt wait in front of the stage barrier.
+#ifndef LWDETR_CONV_ABL
+#define LWDETR_CONV_ABL 0
+#endif
+// One 16-byte fragment read the compiler does not track (counted lgkmcnt waits below; a tracked read that crosses the back edge
+// of the k-loop makes hipcc wait with lgkmcnt(0) in front of the first MFMA of every chunk, i.e. for the reads it has just issued
+// for the NEXT chunk: no overlap at all - 1150 cycles per stage for 256 cycles of MFMA, profiles/r3e_conv3x3_patch.txt).
+template <typename V8>
+__device__ __forceinline__ void lds_read16(V8& dst, unsigned lds_addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr)); }
+// n / dvs for n < 2^31 with magic = floor(2^32 / dvs) (the estimate is at most one too small)
+__device__ __forceinline__ void divmod_magic(unsigned n, unsigned dvs, unsigned magic, unsigned& q, unsigned& r) {
+    q = __umulhi(n, magic); r = n - q * dvs;
+    if (r >= dvs) { ++q; r -= dvs; }
+}
+
 template <typename T, int CIN, int BN, int NST>
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_desc d, int np_patch) {
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_desc d, int np_patch, unsigned magic_hw, unsigned magic_w) {
     constexpr int BM = 128, KB = 32, EPC = 8;
     constexpr int SPR = CIN / EPC + 1, RS = SPR * EPC;      // slots / elements per patch row (one pad slot)
     constexpr int NCH = CIN / KB;                           // stages per tap
     constexpr int B_MY = BN / 16 / 4;                       // weight pieces (16 rows x 64 B) per wave and stage
-    constexpr int WN = BN / 2, TM = 2, TN = WN / 32;
+    constexpr int WN = BN / 2, TM = 2, TN = WN / 32, NRD = TM + TN;       // fragment reads per 16-deep chunk
     typedef typename Vec<T>::v8 V8;
     static_assert(sizeof(T) == 2 && BN % 64 == 0 && CIN % KB == 0, "16-bit, whole pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
     T* patch = (T*)conv_smem;
     T* ring = patch + (long)np_patch * 512;                 // np_patch pieces of 1 KB
+    const unsigned lds_patch = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)conv_smem;
+    const unsigned lds_ring = lds_patch + (unsigned)np_patch * 1024u;
 
     const int nwg = gridDim.x;
     int wg;
@@ -660,7 +688,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_de
         const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;      // neighbouring tiles (shared halo) on one XCD
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const long m0 = (long)wg * BM;
+    const int m0 = wg * BM;                                 // the launcher bounds M * lda * 2 (and M) below 2^31
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -668,6 +696,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_de
     const T* __restrict__ A = (const T*)d.A + d.a_col0;
     const T* __restrict__ W = (const T*)d.W;
     const T* zero = (const T*)g_zero16;
+#ifdef LWDETR_CONV_TIMING
+    const unsigned long long ct0 = CONV_NOW(); unsigned long long ct_lgkm = 0, ct_vm = 0, ct_bar = 0;
+#endif
 
     // ---- weight ring: stage image of gemm_big_kernel at KB = 32 (16-byte slot c of row r at slot c ^ ((r >> 2) & 3))
     const int prow = lane >> 2, pslot = lane & 3;
@@ -681,43 +712,60 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_de
     auto stage = [&](int kt, int slot) {
         T* Bs = ring + slot * (BN * KB);
 #pragma unroll
-        for (int k = 0; k < B_MY; ++k) gdma16((kt < nk && w_src[k]) ? w_src[k] + kt * KB : zero, Bs + (wave + 4 * k) * 64 * EPC);
+        for (int k = 0; k < B_MY; ++k) {
+            if (LWDETR_CONV_ABL & 8) continue;
+            gdma16((kt < nk && w_src[k]) ? w_src[k] + kt * KB : zero, Bs + (wave + 4 * k) * 64 * EPC);
+        }
     };
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s) stage(s, s);
-    // ---- the patch: piece p = 64 consecutive 16-byte slots of the padded row image
-    for (int p = wave; p < np_patch; p += 4) {
-        const int q = p * 64 + lane, pr = q / SPR, ps = q - pr * SPR;
-        const long gm = m0 - Wimg - 1 + pr;
-        const bool ok = ps < SPR - 1 && pr < PR && gm >= 0 && gm < d.M;
-        gdma16(ok ? A + gm * d.lda + ps * EPC : zero, patch + (long)p * 512);
+    for (int s = 0; s < NST; ++s) stage(s, s);
+    // ---- the patch: piece p = 64 consecutive 16-byte slots of the padded row image (slot q: row q / SPR, column q % SPR)
+    {
+        constexpr unsigned MAGIC_SPR = 0x100000000ull / SPR;
+        constexpr int DR = 256 / SPR, DS = 256 - DR * SPR;           // a wave's next piece is 256 slots on: DR rows and DS slots
+        const int lda = (int)d.lda, gm0 = m0 - Wimg - 1;
+        unsigned pr, ps;
+        divmod_magic((unsigned)(wave * 64 + lane), SPR, MAGIC_SPR, pr, ps);
+        int goff = (gm0 + (int)pr) * lda + (int)ps * EPC;            // element offset of this lane's slot in A
+        for (int p = wave; p < np_patch; p += 4) {
+            const int gm = gm0 + (int)pr;
+            const bool ok = ps < SPR - 1 && (int)pr < PR && gm >= 0 && gm < d.M;
+            if (!(LWDETR_CONV_ABL & 2)) gdma16(ok ? A + goff : zero, patch + p * 512);
+            pr += DR; ps += DS; goff += DR * lda + DS * EPC;
+            if (ps >= SPR) { ps -= SPR; ++pr; goff += lda - SPR * EPC; }
+        }
     }
-
+#ifdef LWDETR_CONV_TIMING
+    const unsigned long long ct1 = CONV_NOW();
+#endif
     // ---- validity of the nine taps for this lane's two pixels; wave-uniform "some lane needs the mask" words
     unsigned vbits[TM], need[TM];
     {
-        const int hw = Himg * Wimg;
+        const unsigned hw = (unsigned)(Himg * Wimg);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const long m = m0 + wm * 64 + i * 32 + l31;
-            const int r = (int)(m % hw), y = r / Wimg, x = r - y * Wimg;
-            unsigned v = 0, nd = 0;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-                const bool ok = iy >= 0 && iy < Himg && ix >= 0 && ix < Wimg;
-                v |= ok ? 1u << tap : 0u;
-                nd |= __builtin_amdgcn_ballot_w64(!ok) != 0 ? 1u << tap : 0u;
-            }
-            vbits[i] = v; need[i] = __builtin_amdgcn_readfirstlane(nd);
+            unsigned qq, r, y, x;
+            divmod_magic((unsigned)(m0 + wm * 64 + i * 32 + l31), hw, magic_hw, qq, r);
+            divmod_magic(r, (unsigned)Wimg, magic_w, y, x);
+            // a tap is outside the image iff it leaves through the pixel's top / bottom / left / right edge: four per-lane flags
+            // and four ballots instead of nine bounds tests and ballots (this prologue ran 1.1 us on a lone wave)
+            const bool top = y == 0, bot = (int)y == Himg - 1, lef = x == 0, rig = (int)x == Wimg - 1;
+            const unsigned row_ok[3] = {top ? 0u : 7u, 7u, bot ? 0u : 7u};                  // taps 3 dy' .. 3 dy' + 2
+            const unsigned col_ok = (lef ? 0u : 0x49u) | 0x92u | (rig ? 0u : 0x124u);        // bit tap: dx' = tap % 3
+            vbits[i] = (row_ok[0] | row_ok[1] << 3 | row_ok[2] << 6) & col_ok;
+            const unsigned at = __builtin_amdgcn_ballot_w64(top) != 0, ab = __builtin_amdgcn_ballot_w64(bot) != 0;
+            const unsigned al = __builtin_amdgcn_ballot_w64(lef) != 0, ar = __builtin_amdgcn_ballot_w64(rig) != 0;
+            need[i] = (at ? 7u : 0u) | (ab ? 7u << 6 : 0u) | (al ? 0x49u : 0u) | (ar ? 0x124u : 0u);
         }
     }
-    const T* a_base[TM];
+    unsigned a_addr[TM], w_addr[TN][2];                     // LDS byte addresses: pixel rows in the patch; weight rows per 16-deep chunk
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a_base[i] = patch + (wm * 64 + i * 32 + l31) * RS + h * EPC;
-    int wrow[TN], wsw[TN];                                   // this lane's weight row inside a stage and its swizzle key
+    for (int i = 0; i < TM; ++i) a_addr[i] = lds_patch + (unsigned)(((wm * 64 + i * 32 + l31) * RS + h * EPC) * (int)sizeof(T));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { wrow[j] = (wn * WN + j * 32 + l31) * KB; wsw[j] = (l31 >> 2) & 3; }
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+            w_addr[j][kc] = lds_ring + (unsigned)(((wn * WN + j * 32 + l31) * KB + ((2 * kc + h) ^ ((l31 >> 2) & 3)) * EPC) * (int)sizeof(T));
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -727,57 +775,147 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_de
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
+    // ---- k-loop, software-pipelined over 16-deep chunks (two per stage). Chunk (kt, 0) multiplies out of one fragment buffer
+    // while the reads of (kt, 1) fill the other; chunk (kt, 1) does the same with the reads of (kt + 1, 0) - so the stage barrier
+    // sits in FRONT of the second chunk of a stage: by then every wave holds the last fragments of stage kt in registers
+    // (lgkmcnt(0): nothing of this wave is still reading the buffer the others are about to refill - without that wait the
+    // refill overtook reads that were queued behind an LDS-heavy neighbour kernel of another stream, tools/conv_stress.py), the
+    // buffer of stage kt is free for stage kt + NST, and stage kt + 1, whose first chunk is read next, must have landed. The
+    // pixel fragments come from the resident patch and depend on no barrier at all.
+#ifdef LWDETR_CONV_TIMING
+    const unsigned long long ct2 = CONV_NOW();
+#endif
     wait_vmcnt<0>();
-    int kt = 0, slot = 0;
+    __builtin_amdgcn_s_barrier();                     // the patch and the first NST stages, everybody's
+#ifdef LWDETR_CONV_TIMING
+    const unsigned long long ct3 = CONV_NOW();
+#endif
+    // reads of chunk kc of the stage in ring buffer `soff` (byte offset), pixel rows at a_tap[] + (c KB + 16 kc) elements
+    auto load = [&](auto c_tag, auto kc_tag, const unsigned (&a_tap)[TM], unsigned soff, V8 (&xf)[TM], V8 (&wf)[TN]) {
+        constexpr int OFF = (decltype(c_tag)::value * KB + decltype(kc_tag)::value * 16) * (int)sizeof(T), KC = decltype(kc_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (LWDETR_CONV_ABL & 16) { for (int e = 0; e < 8; ++e) wf[j][e] = (T)(float)(j + e); asm volatile("" : "+v"(wf[j])); continue; }
+            lds_read16(wf[j], w_addr[j][KC] + soff);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (LWDETR_CONV_ABL & 16) { for (int e = 0; e < 8; ++e) xf[i][e] = (T)(float)(i - e); asm volatile("" : "+v"(xf[i])); continue; }
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[i]) : "v"(a_tap[i]), "n"(OFF));
+        }
+    };
+    // the fragments of a chunk are in their registers once at most `pending` younger reads are outstanding; the empty statements
+    // tie the MFMAs (and the masks) below to the wait
+    auto landed = [&](auto pending, V8 (&xf)[TM], V8 (&wf)[TN]) {
+        constexpr int P = decltype(pending)::value;
+        if (!(LWDETR_CONV_ABL & 16)) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(P) : "memory");
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(xf[i]));
+    };
+    auto mma = [&](const unsigned (&nd)[TM], const unsigned (&keep)[TM], V8 (&xf)[TM], V8 (&wf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            if (nd[i]) {                              // wave-uniform: some lane's tap falls outside its image
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                u32x4v u = __builtin_bit_cast(u32x4v, xf[i]);
+                u = u & keep[i];
+                xf[i] = __builtin_bit_cast(V8, u);
+            }
+        if (LWDETR_CONV_ABL & 1) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(wf[j]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(xf[i]));
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = Mma32<T>::k16(wf[j], xf[i], acc[j][i]);
+    };
+    auto tap_rows = [&](int tap, unsigned (&a_tap)[TM]) {
+        const unsigned toff = (unsigned)((Wimg + 1 + (tap / 3 - 1) * Wimg + (tap % 3 - 1)) * RS * (int)sizeof(T));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_tap[i] = a_addr[i] + toff;
+    };
+    constexpr unsigned SLOT_B = BN * KB * sizeof(T);
+    V8 xa[TM], wa[TN], xb[TM], wb[TN];
+    unsigned a_cur[TM], a_nxt[TM];
+    tap_rows(0, a_cur);
+    load(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_cur, 0u, xa, wa);
+    int kt = 0;
+    unsigned soff = 0;                                // ring buffer of stage kt
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-        const int toff = (Wimg + 1 + (tap / 3 - 1) * Wimg + (tap % 3 - 1)) * RS;
-        unsigned keep[TM];
+        tap_rows(tap + 1, a_nxt);                     // (tap 9 is never read)
+        unsigned nd[TM], keep[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) keep[i] = (vbits[i] >> tap) & 1 ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            // every fragment read of stage kt - 1 has RETURNED before this wave lets the others refill that buffer: the DMA is
-            // invisible to hipcc, which is free to sink the MFMAs of the previous stage - and with them the lgkmcnt wait of their
-            // operands - below the barrier (seen beside LDS-heavy kernels of another stream: reads queued behind the
-            // neighbours' LDS traffic were overtaken by the refill; tools/conv_stress.py)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wait_vmcnt<(NST - 2) * B_MY>();                   // stage kt has landed (this wave's pieces) ...
-            __builtin_amdgcn_s_barrier();                     // ... and everybody's (first pass: the patch too); stage kt - 1 is free
+        for (int i = 0; i < TM; ++i) { nd[i] = (need[i] >> tap) & 1; keep[i] = (vbits[i] >> tap) & 1 ? 0xffffffffu : 0u; }
+        auto one_stage = [&](auto c_tag) {
+            constexpr int C = decltype(c_tag)::value;
+            load(c_tag, std::integral_constant<int, 1>{}, a_cur, soff, xb, wb);
+            landed(std::integral_constant<int, NRD>{}, xa, wa);
+            mma(nd, keep, xa, wa);
+#ifdef LWDETR_CONV_TIMING
+            const unsigned long long cta = CONV_NOW();
+#endif
+            landed(std::integral_constant<int, 0>{}, xb, wb);  // ... and no read of stage kt is in flight any more
+#ifdef LWDETR_CONV_TIMING
+            const unsigned long long ctb = CONV_NOW();
+#endif
+            wait_vmcnt<(NST - 2) * B_MY>();           // stage kt + 1 has landed (this wave's pieces) ...
+#ifdef LWDETR_CONV_TIMING
+            const unsigned long long ctc = CONV_NOW();
+#endif
+            __builtin_amdgcn_s_barrier();             // ... and everybody's; everybody holds the last fragments of stage kt
+#ifdef LWDETR_CONV_TIMING
+            ct_lgkm += ctb - cta; ct_vm += ctc - ctb; ct_bar += CONV_NOW() - ctc;
+#endif
             {
-                int ns = slot + NST - 1; ns = ns >= NST ? ns - NST : ns;
-                stage(kt + NST - 1, ns);
-            }
-            const T* Bs = ring + slot * (BN * KB);
+                T* Bs = (T*)((unsigned char*)ring + soff);
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {                  // two 16-deep MFMA steps per stage
-                V8 xf[TM], wf[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wf[j] = *(const V8*)(Bs + wrow[j] + ((2 * kc + h) ^ wsw[j]) * EPC);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    xf[i] = *(const V8*)(a_base[i] + toff + c * KB + kc * 16);
-                    if ((need[i] >> tap) & 1) {
-                        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-                        u32x4v u = __builtin_bit_cast(u32x4v, xf[i]);
-                        u = u & keep[i];
-                        xf[i] = __builtin_bit_cast(V8, u);
-                    }
+                for (int k = 0; k < B_MY; ++k) {
+                    if (LWDETR_CONV_ABL & 8) continue;
+                    gdma16((kt + NST < nk && w_src[k]) ? w_src[k] + (kt + NST) * KB : zero, Bs + (wave + 4 * k) * 64 * EPC);
                 }
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) acc[j][i] = Mma32<T>::k16(wf[j], xf[i], acc[j][i]);
             }
-            ++kt; slot = slot + 1 == NST ? 0 : slot + 1;
-        }
+            soff = soff + SLOT_B == NST * SLOT_B ? 0u : soff + SLOT_B;
+            ++kt;
+            // first chunk of the next stage: the next tap's rows after the last stage of this one
+            if constexpr (C + 1 < NCH) load(std::integral_constant<int, C + 1>{}, std::integral_constant<int, 0>{}, a_cur, soff, xa, wa);
+            else if (tap < 8) load(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_nxt, soff, xa, wa);
+            mma(nd, keep, xb, wb);
+        };
+        one_stage(std::integral_constant<int, 0>{});
+        one_stage(std::integral_constant<int, 1>{});
+        one_stage(std::integral_constant<int, 2>{});
+        one_stage(std::integral_constant<int, 3>{});
+        if constexpr (NCH > 4) { one_stage(std::integral_constant<int, 4>{}); one_stage(std::integral_constant<int, 5>{}); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_cur[i] = a_nxt[i];
     }
+#ifdef LWDETR_CONV_TIMING
+    const unsigned long long ct4 = CONV_NOW();
+#endif
     wait_vmcnt<0>();            // the dummy tail pieces
     __syncthreads();            // ... and everybody's last fragment reads, before the patch becomes the epilogue's staging area
     // ---- epilogue: 64 rows per pass through the f32 stage area (aliases the patch), finished by all 256 threads.
     // 32x32 accumulator: register 4 q + r of lane (c = lane & 31, hi) is element (row 8 q + 4 hi + r, column c) of D = W x pixels.
     float* stg = (float*)conv_smem;
     constexpr int SLD = BN + 4;
+    if (LWDETR_CONV_ABL & 4) {
+        float keepalive = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) keepalive += acc[j][i][e];
+        if (keepalive == 123.456f) stg[0] = 1.f;
+        return;
+    }
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (wm == pass) {
@@ -795,6 +933,13 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_de
         epilogue_finish<T, BN, 256>(d, d.seg[0], false, stg, m0 + pass * 64, 0);
         __syncthreads();
     }
+#ifdef LWDETR_CONV_TIMING
+    if (wg == LWDETR_CONV_TIMING && lane == 0) {
+        unsigned long long* o = g_conv_timing[wave];
+        const unsigned long long ct5 = CONV_NOW();
+        o[0] = ct1 - ct0; o[1] = ct2 - ct1; o[2] = ct3 - ct2; o[3] = ct4 - ct3; o[4] = ct5 - ct4; o[5] = ct_lgkm; o[6] = ct_vm; o[7] = ct_bar; o[8] = ct5 - ct0;
+    }
+#endif
 }
 
 // ---- A-panel-resident variant (16-bit, plain A, K <= 768): one workgroup owns BM rows and ALL N columns. The BM x K panel
@@ -1166,7 +1311,9 @@ int launch_conv_patch(const lwdetr_gemm_desc& d, hipStream_t st) {
         state[dev] = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<T, CIN, CIN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : -1;
     if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
     const long nwg = (d.M + 127) / 128;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, CIN, NST>), dim3((unsigned)nwg), dim3(256), lds, st, d, np);
+    const unsigned hw = (unsigned)(d.conv_hout * d.conv_wout);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<T, CIN, CIN, NST>), dim3((unsigned)nwg), dim3(256), lds, st, d, np,
+                       (unsigned)(0x100000000ull / hw), (unsigned)(0x100000000ull / (unsigned)d.conv_wout));
     return lwdetr_check_launch();
 }
 
@@ -1185,10 +1332,15 @@ int try_launch_conv_patch(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken
         const long hw = (long)d.conv_hout * d.conv_wout;
         if (d.conv_stride != 1 || d.a_tok.winmajor || d.a_tok.Hp != d.conv_hout || d.a_tok.Wp != d.conv_wout || d.nseg != 1 ||
             g.mode != LWDETR_OUT_LINEAR || d.N != d.conv_cin || d.K != 9 * d.conv_cin || (d.N != 128 && d.N != 192) ||
-            d.lda % 8 != 0 || d.a_col0 % 8 != 0 || ((size_t)d.A & 15) != 0 || ((size_t)d.W & 15) != 0 || hw <= 0 || d.M % hw != 0 ||
-            d.M / 128 > 0x7ffffff0L)
+            d.lda % 8 != 0 || d.a_col0 % 8 != 0 || ((size_t)d.A & 15) != 0 || ((size_t)d.W & 15) != 0 || hw <= 1 || d.M % hw != 0 ||
+            d.conv_wout < 2 || (long)(d.M + 256) * d.lda >= (1L << 30))       // 32-bit element offsets into A
             return LWDETR_OK;
-        const int rc = d.N == 128 ? launch_conv_patch<T, 128, 3>(d, st) : launch_conv_patch<T, 192, 3>(d, st);
+        const char* nenv = getenv("LWDETR_CONV_PATCH_NST");       // tuning: ring depth
+        const int nst = nenv ? atoi(nenv) : 3;
+        int rc;
+        if (d.N == 128) rc = nst == 4 ? launch_conv_patch<T, 128, 4>(d, st) : nst == 6 ? launch_conv_patch<T, 128, 6>(d, st) :
+                             nst == 8 ? launch_conv_patch<T, 128, 8>(d, st) : launch_conv_patch<T, 128, 3>(d, st);
+        else rc = launch_conv_patch<T, 192, 3>(d, st);
         taken = rc != LWDETR_ERR_UNSUPPORTED;
         return taken ? rc : LWDETR_OK;
     }

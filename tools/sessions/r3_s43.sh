@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3, GPU session 43: convolution prologue trimmed; tests, stress, timing, model bench, chain tests
+set -u
+OUT=gpurun_out/r3_s43; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "conv3x3" 2>&1 | tail -1
+timeout 300 python tools/conv_stress.py 20 2>&1 | grep -v amdgpu | grep "^load\|idle" | cut -c1-200
+python tools/conv_time.py 16 32 2>&1 | grep -v amdgpu
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_chains.py -x -q -m gpu 2>&1 | tail -1
+for cfg in "--size small --batch 32 --dtype fp16" "--size medium --batch 64 --dtype bf16"; do
+  timeout 600 python bench.py $cfg --no-cpu-baseline --no-latency > $OUT/bench_$(echo $cfg | cut -d' ' -f2).json 2> $OUT/bench.err
+  python -c "
+import json,sys;r=json.loads(open('$OUT/bench_$(echo $cfg | cut -d' ' -f2).json').read().strip().splitlines()[-1]);print(r['config']['workload'][:40], r['value'], r['ms_per_step']);print({k:round(v['ms_per_step'],3) for k,v in list(r['kernels'].items())[:9]})"
+done
