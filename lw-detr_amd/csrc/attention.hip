@@ -675,6 +675,166 @@ static bool lds_path_applies(const lwdetr_attn_desc& p) {
            (p.sub_len == p.sub_stride || p.sub_stride >= 64);
 }
 
+// =====================================================================================================================
+// Short-sequence variant (window attention at 640 x 640: 100 keys; any sequence of <= 128 keys, hd 16 / 32, 16-bit types).
+// ONE WAVE owns a whole (sequence, head): its K and V^T live in registers as MFMA operand fragments for the whole kernel
+// (4 + 8 fragments at hd 16), each 32-query tile is S^T = K Q^T (32x32x16, the contraction IS hd at hd 16: no padding) ->
+// row maximum over the lane's registers + one half-wave exchange -> exp2 -> P packed in place as the B operand of
+// O^T = V^T P^T (k-slot (h, j) of 16-key chunk c is key 16 c + 8 (j >> 2) + 4 h + (j & 3): V^T is loaded in that order) ->
+// normalise -> half-wave exchange to 8 consecutive channels per lane -> 16-byte stores. At hd 16 rows 16-31 of the V^T operand
+// are free: row 16 is all ones, so the softmax denominator drops out of the same MFMAs. attn_kernel spreads a 100-key window
+// over 4 waves that each re-load K and V^T and run 4 dependent load -> MFMA -> softmax -> MFMA steps (19 us at B = 16 for
+// 40 MB of q / k / v / out, 2.4x the HBM floor; tools/attn_bench.py); here a wave issues all its loads at once.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_win_kernel(const lwdetr_attn_desc p) {
+    typedef typename Vec<T>::v8 V8;
+    typedef typename Vec<T>::v4 V4;
+    constexpr int NC = HD / 16;                         // 16-deep chunks of the Q K^T contraction
+    constexpr int RT = HD / 32 > 0 ? HD / 32 : 1;      // 32-row tiles of the output channels (hd 16: half a tile + the ones row)
+    static_assert(sizeof(T) == 2 && (HD == 16 || HD == 32), "16-bit types, hd 16 / 32");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+    const long npairs = (long)p.B * p.heads * p.seqs_per_img;
+    const long pair = (long)blockIdx.x * 4 + wave;      // (image, head, window): the four waves of a workgroup are neighbours in memory
+    if (pair >= npairs) return;
+    const int w = (int)(pair % p.seqs_per_img);
+    const long bh = pair / p.seqs_per_img;
+    const int head = (int)(bh % p.heads), b = (int)(bh / p.heads);
+    const long tok0 = (long)w * p.seq_tok_stride;
+    const T* __restrict__ Qb = (const T*)p.Q + (bh * p.Tp + tok0) * HD;
+    const T* __restrict__ Kb = (const T*)p.K + (bh * p.Tp + tok0) * HD;
+    const T* __restrict__ Vb = (const T*)p.VT + bh * HD * (long)p.Tp + tok0;
+    const int nkeys = p.keys_per_seq, last = nkeys - 1;
+    const int nvalid = p.sub_len < nkeys ? p.sub_len : nkeys;        // pad rows sit behind the real tokens (one sub-window)
+    const int nqt = (nkeys + 31) >> 5, nkt = (nvalid + 31) >> 5, nch = (nvalid + 15) >> 4;
+
+    // ---- everything this wave will ever read, issued at once
+    V8 kf[4][NC], vf[8][RT], qf[4][NC];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        int key = kt * 32 + l31; key = key < last ? key : last;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) kf[kt][c] = *(const V8*)(Kb + (long)key * HD + c * 16 + h * 8);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        int q = qt * 32 + l31; q = q < last ? q : last;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qf[qt][c] = *(const V8*)(Qb + (long)q * HD + c * 16 + h * 8);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int row = r * 32 + l31;              // output channel (hd 16: rows 16-31 are not channels)
+            V8 v;
+            if (HD == 16 && row >= 16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(row == 16 ? 1.f : 0.f);
+            } else {
+                // runs of 4 keys; a run past the end is clamped to the last run (finite values; its P is exactly 0)
+                int k0 = 16 * c + 4 * h, k1 = k0 + 8;
+                k0 = k0 + 4 <= nkeys ? k0 : nkeys - 4; k1 = k1 + 4 <= nkeys ? k1 : nkeys - 4;
+                const V4 lo = *(const V4*)(Vb + (long)row * p.Tp + k0), hi = *(const V4*)(Vb + (long)row * p.Tp + k1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+            }
+            vf[c][r] = v;
+        }
+    }
+
+    T* __restrict__ out = (T*)p.out;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        if (qt >= nqt) break;                           // wave-uniform
+        // ---- S^T tile by tile: register 4 b + e of lane (query l31, h) is key 32 kt + 8 b + 4 h + e
+        f32x16 sc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nkt) break;
+            f32x16 a;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) a = Mma32<T>::k16(kf[kt][c], qf[qt][c], a);
+            if (kt * 32 + 32 > nvalid) {                // the ragged last tile: keys past the real tokens
+                asm volatile("; ragged key tile");      // keeps this a branch: hipcc otherwise runs the 16 compares + selects on every tile
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a[e] = kt * 32 + 8 * (e >> 2) + 4 * h + (e & 3) < nvalid ? a[e] : -INFINITY;
+            }
+            sc[kt] = a;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nkt) break;
+            float lm = max3(sc[kt][0], sc[kt][1], sc[kt][2]);
+#pragma unroll
+            for (int e = 3; e < 15; e += 2) lm = max3(lm, sc[kt][e], sc[kt][e + 1]);
+            mx = max3(mx, lm, sc[kt][15]);
+        }
+        mx = xor32_max(mx);                             // both halves of the query's keys
+        // ---- P = exp2(S - max), packed per 16-key chunk as the B operand; O^T = V^T P^T
+        f32x16 o[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[r][e] = 0.f;
+        float lsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c >= nch) break;
+            V8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(sc[c >> 1][8 * (c & 1) + e] - mx);
+                if (HD > 16) lsum += pe;
+                pf[e] = from_f32<T>(pe);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) o[r] = Mma32<T>::k16(vf[c][r], pf, o[r]);
+        }
+        // ---- normalise; register 4 b + e of lane (query, h) is channel 8 b + 4 h + e (hd 16: the ones row is channel 16 = b 2, h 0, e 0)
+        float inv;
+        if (HD == 16) {
+            const auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[0][8]), __float_as_uint(o[0][8]), false, false);
+            inv = 1.f / (h == 0 ? o[0][8] : __uint_as_float(rr[0]));       // r[0] of an upper lane is the lower half's value
+        } else {
+            inv = 1.f / xor32_sum(lsum);
+        }
+        const int q = qt * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+#pragma unroll
+            for (int bp = 0; bp < (HD == 16 ? 1 : 2); ++bp) {      // pairs of 4-channel blocks (b = 2 bp, 2 bp + 1): channels 16 bp + 4 h + .., 16 bp + 8 + 4 h + ..
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                V4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = from_f32<T>(o[r][8 * bp + e] * inv); hi[e] = from_f32<T>(o[r][8 * bp + 4 + e] * inv); }
+                const u32x2 lu = __builtin_bit_cast(u32x2, lo), hu = __builtin_bit_cast(u32x2, hi);
+                // lower lanes keep lo (channels 0-3) and take the upper lanes' lo (4-7); upper lanes take the lower lanes' hi (8-11) and keep hi
+                const auto s0 = __builtin_amdgcn_permlane32_swap(lu[0], hu[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(lu[1], hu[1], false, false);
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                const u32x4v st = {s0[0], s1[0], s0[1], s1[1]};
+                if (q < nkeys)
+                    *(u32x4v*)(out + ((long)b * p.Tp + tok0 + q) * p.ldo + head * HD + r * 32 + 16 * bp + 8 * h) = st;
+            }
+        }
+    }
+}
+
+template <typename T, int HD>
+int launch_win(const lwdetr_attn_desc& p, hipStream_t st) {
+    const long npairs = (long)p.B * p.heads * p.seqs_per_img;
+    const double nseq = (double)p.B * p.seqs_per_img;
+    const double flops = 4.0 * nseq * p.heads * (double)p.keys_per_seq * p.keys_per_seq * HD;
+    const double bytes = 4.0 * nseq * p.heads * p.keys_per_seq * HD * sizeof(T);
+    const int kid = p.kind == 0 ? KID_ATTN_WINDOW : (p.kind == 1 ? KID_ATTN_GLOBAL : KID_ATTN_DECODER);
+    ProfScope ps(kid, flops, bytes, st);
+    hipLaunchKernelGGL((attn_win_kernel<T, HD>), dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, st, p);
+    return lwdetr_check_launch();
+}
+
 template <typename T, int HD, int QT>
 int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
     const int units = (p.keys_per_seq + 16 * QT - 1) / (16 * QT);
@@ -690,6 +850,18 @@ int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
 
 template <typename T, int HD>
 int launch(const lwdetr_attn_desc& p, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && (HD == 16 || HD == 32)) {
+        // one wave per (sequence, head): sequences of at most 128 keys whose pad rows sit behind the real tokens.
+        // Measured (tools/attn_bench.py, us per launch, attn_kernel | this kernel): hd 32, 100-key windows, medium B = 64 bf16
+        // 108 | 82, large B = 32 fp16 51 | 41; hd 16 (small, B = 16 / 32): 20.4 | 22.0, 32.8 | 36.1 - both forms run their loads
+        // and their exp-bound arithmetic in lockstep there and the four-wave form spreads the arithmetic wider.
+        // LWDETR_ATTN_WIN: 0 = never, 1 = whenever legal (tests), default = hd 32 only.
+        const char* env = getenv("LWDETR_ATTN_WIN");
+        const int mode = env ? atoi(env) : 2;
+        if (mode != 0 && (mode == 1 || HD == 32) && p.keys_per_seq <= 128 && p.sub_stride >= p.keys_per_seq && p.ldo % 8 == 0 &&
+            ((size_t)p.out & 15) == 0 && (long)p.B * p.heads * p.seqs_per_img / 4 < 0x7fffffffL)
+            return launch_win<T, HD>(p, st);
+    }
     if (LdsPath<T, HD>::ok(p) && lds_path_applies(p)) return LdsPath<T, HD>::go(p, st);
     // long sequences: 64 queries per wave (K / V^T fragments amortised over 4 query tiles); short ones keep 32 so a
     // 100-token window still spreads over 4 waves

@@ -278,6 +278,38 @@ def test_attention(dtype, hd, geom):
     assert err < {torch.float32: 2e-5, torch.float16: 6e-3, torch.bfloat16: 4e-2}[dtype], err
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("hd", [16, 32])
+@pytest.mark.parametrize("twp,tw,spi,b,heads", [(100, 100, 16, 2, 3), (28, 25, 16, 1, 3), (128, 126, 3, 1, 3), (36, 36, 16, 1, 2), (8, 5, 5, 1, 1),
+                                                 (64, 64, 16, 1, 4), (100, 97, 16, 1, 2)])
+def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkeypatch):
+    """attn_win_kernel (sequences of <= 128 keys, one wave per (sequence, head)) vs the fp32 formulation and vs attn_kernel:
+    pad rows behind the real tokens, ragged key / query tiles, a partially filled last workgroup, 8 keys."""
+    from lwdetr_amd import kernels as K
+    tp = spi * twp
+    q = _rand(b, heads, tp, hd, dtype=dtype, seed=1)
+    k = _rand(b, heads, tp, hd, dtype=dtype, seed=2)
+    v = _rand(b, heads, tp, hd, dtype=dtype, seed=3)
+    k[0, 0, tw - 1] = q[0, 0, 2] * 4                  # a dominant key in the ragged last tile
+    qs = (q.float() * K.attention_scale(hd)).to(dtype)
+    vt = v.transpose(2, 3).contiguous()
+    outs = []
+    for win in ("1", "0"):
+        monkeypatch.setenv("LWDETR_ATTN_WIN", win)
+        out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())
+        K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd, seqs_per_img=spi, seq_tok_stride=twp,
+                 keys_per_seq=twp, sub_stride=twp, sub_len=tw, kind=0)()
+        outs.append(out.reshape(b, tp, heads, hd).permute(0, 2, 1, 3).float())
+    qn = qs.float() / math.log2(math.e)
+    valid = (torch.arange(tp, device=_dev()) % twp) < tw
+    ref = torch.cat([_attn_ref(qn[:, :, wi * twp:(wi + 1) * twp], k[:, :, wi * twp:(wi + 1) * twp], v[:, :, wi * twp:(wi + 1) * twp],
+                               valid[wi * twp:(wi + 1) * twp]) for wi in range(spi)], 2)
+    e_new = ((outs[0] - ref)[:, :, valid]).abs().max().item()
+    e_old = ((outs[1] - ref)[:, :, valid]).abs().max().item()
+    assert e_new < {torch.float16: 6e-3, torch.bfloat16: 4e-2}[dtype] and e_new < 1.5 * e_old + 1e-4, (e_new, e_old)
+    assert torch.isfinite(outs[0]).all()              # pad rows are written too (finite)
+
+
 @pytest.fixture
 def big_gemm():
     """Route every legal GEMM through the 256-row large-tile kernel (by default only large shapes take it)."""
