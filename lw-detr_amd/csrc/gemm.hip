@@ -1328,6 +1328,9 @@ int try_launch_conv_patch(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken
         // N = Cin = 192 (the C = 384 models: 117-153 KB of LDS, one workgroup per CU) measured SLOWER than the 256-row large-tile
         // kernel with its 192-wide column tile (large, B = 32: 16 launches 2.24 vs 1.93 ms per step) - off unless asked for
         if (mode == 1 && d.N != 128) return LWDETR_OK;
+        // one workgroup per 128 pixels walks all 9 Cin / 32 stages by itself: below ~100 workgroups (a single 640 x 640 image has
+        // 13) the 64 x 64 ring kernel's 4x finer grid finishes sooner
+        if (mode == 1 && d.M < 100 * 128) return LWDETR_OK;
         const lwdetr_gemm_seg& g = d.seg[0];
         const long hw = (long)d.conv_hout * d.conv_wout;
         if (d.conv_stride != 1 || d.a_tok.winmajor || d.a_tok.Hp != d.conv_hout || d.a_tok.Wp != d.conv_wout || d.nseg != 1 ||

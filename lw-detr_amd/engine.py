@@ -402,16 +402,45 @@ class ForwardPlan:
         ld_oa = _ceil4(lp3)
         oa = z(rq, ld_oa)
         self.dec_bufs = dict(xdec=self.xdec, qpos=self.qpos, q=qd, k=kd, vt=vtd, att=attd, y=y, ca=ca, oa=oa, hs=self.hs)   # tools/determinism_probe.py
+        # query_pos is the same in every layer (lite_refpoint_refine: the reference points are not refined between layers,
+        # transformer.py:300-330), and it only ever enters a layer through (x + query_pos) W: the products query_pos Wq^T,
+        # query_pos Wk^T and query_pos [W_offsets; W_weights]^T of ALL layers come out of ONE GEMM up front, and each layer adds
+        # its slice in the epilogue of x W (the `res` term; the q slice is pre-multiplied by the attention scale through `gamma`).
+        # Per layer that merges the q / k and v projections into one launch and takes the A + A2 operand sum (no LDS-DMA path)
+        # out of the two GEMMs that had it. LWDETR_DEC_QPOS=0 keeps the round-2 plan (A2 = query_pos).
+        qpos_pre = os.environ.get("LWDETR_DEC_QPOS", "1") != "0" and ld_oa % 8 == 0 and (2 * d) % 128 == 0
+        if qpos_pre:
+            s_att = K.attention_scale(sa_hd)
+            w_pre = pw.custom(f"{t}.decoder.qpos_pre.w", lambda: torch.cat(
+                [pw.sd[f"{t}.decoder.layers.{i}.self_attn.in_proj_weight"].detach().float()[:2 * d] for i in range(nl)] +
+                [F.pad(torch.cat([pw.sd[f"{t}.decoder.layers.{i}.cross_attn.sampling_offsets.weight"].detach().float(),
+                                  pw.sd[f"{t}.decoder.layers.{i}.cross_attn.attention_weights.weight"].detach().float()], 0),
+                       (0, 0, 0, ld_oa - lp3)) for i in range(nl)], 0))
+            g_pre = pw.custom(f"{t}.decoder.qpos_pre.gamma", lambda: torch.cat(
+                [torch.full((d,), s_att), torch.ones(d)] * nl), dtype=torch.float32)
+            pqk, poa = z(rq, nl * 2 * d), z(rq, nl * ld_oa)
+            ops.append(GemmOp(self.qpos, w_pre, rq, nl * (2 * d + ld_oa), d, [
+                seg(pqk, 0, nl * 2 * d, ldo=nl * 2 * d, gamma=g_pre),
+                seg(poa, nl * 2 * d, nl * (2 * d + ld_oa), ldo=nl * ld_oa)]))
         for li in range(nl):
             lay = f"{t}.decoder.layers.{li}"
             ipw, ipb = lay + ".self_attn.in_proj_weight", lay + ".self_attn.in_proj_bias"
-            ops.append(GemmOp(self.xdec, pw.w(ipw, lambda w_: w_[:2 * d], "qk"), rq, 2 * d, d, [
-                seg(qd, 0, d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[:d], "q"), scale=K.attention_scale(sa_hd),
-                    p0=nq, p1=sa_hd, p2=sa_h),
-                seg(kd, d, 2 * d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[d:2 * d], "k"), p0=nq, p1=sa_hd, p2=sa_h)],
-                A2=self.qpos))
-            ops.append(GemmOp(self.xdec, pw.w(ipw, lambda w_: w_[2 * d:], "v"), rq, d, d, [
-                seg(vtd, 0, d, mode=OUT_HEADS_T, bias=pw.f(ipb, lambda b_: b_[2 * d:], "v"), p0=nq, p1=sa_hd, p2=sa_h)]))
+            if qpos_pre:
+                ops.append(GemmOp(self.xdec, pw.w(ipw), rq, 3 * d, d, [
+                    seg(qd, 0, d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[:d], "q"), scale=s_att, p0=nq, p1=sa_hd, p2=sa_h,
+                        res=pqk[:, li * 2 * d:], ldres=nl * 2 * d),
+                    seg(kd, d, 2 * d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[d:2 * d], "k"), p0=nq, p1=sa_hd, p2=sa_h,
+                        res=pqk[:, li * 2 * d + d:], ldres=nl * 2 * d),
+                    seg(vtd, 2 * d, 3 * d, mode=OUT_HEADS_T, bias=pw.f(ipb, lambda b_: b_[2 * d:], "v"), p0=nq, p1=sa_hd, p2=sa_h)],
+                    keep=(pqk,)))
+            else:
+                ops.append(GemmOp(self.xdec, pw.w(ipw, lambda w_: w_[:2 * d], "qk"), rq, 2 * d, d, [
+                    seg(qd, 0, d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[:d], "q"), scale=K.attention_scale(sa_hd),
+                        p0=nq, p1=sa_hd, p2=sa_h),
+                    seg(kd, d, 2 * d, mode=OUT_HEADS, bias=pw.f(ipb, lambda b_: b_[d:2 * d], "k"), p0=nq, p1=sa_hd, p2=sa_h)],
+                    A2=self.qpos))
+                ops.append(GemmOp(self.xdec, pw.w(ipw, lambda w_: w_[2 * d:], "v"), rq, d, d, [
+                    seg(vtd, 0, d, mode=OUT_HEADS_T, bias=pw.f(ipb, lambda b_: b_[2 * d:], "v"), p0=nq, p1=sa_hd, p2=sa_h)]))
             ops.append(AttnOp(qd, kd, vtd, attd, B=B, heads=sa_h, hd=sa_hd, Tp=nq, ldo=d, seqs_per_img=1,
                               seq_tok_stride=nq, keys_per_seq=nq, sub_stride=nq, sub_len=nq, kind=2))
             ops.append(GemmOp(attd, pw.w(lay + ".self_attn.out_proj.weight"), rq, d, d, [
@@ -424,7 +453,11 @@ class ForwardPlan:
             b_oa = pw.custom(ca_p + ".oa.b", lambda ca_p=ca_p: torch.cat(
                 [pw.sd[ca_p + ".sampling_offsets.bias"].detach().float(),
                  pw.sd[ca_p + ".attention_weights.bias"].detach().float()], 0), dtype=torch.float32)
-            ops.append(GemmOp(self.xdec, w_oa, rq, lp3, d, [seg(oa, 0, lp3, ldo=ld_oa, bias=b_oa)], A2=self.qpos))
+            if qpos_pre:
+                ops.append(GemmOp(self.xdec, w_oa, rq, lp3, d, [seg(oa, 0, lp3, ldo=ld_oa, bias=b_oa, res=poa[:, li * ld_oa:],
+                                                                     ldres=nl * ld_oa)], keep=(poa,)))
+            else:
+                ops.append(GemmOp(self.xdec, w_oa, rq, lp3, d, [seg(oa, 0, lp3, ldo=ld_oa, bias=b_oa)], A2=self.qpos))
             ops.append(MsdaFusedOp(self.values[li], self.shapes_t, self.lsi_t, oa, ld_oa, M * L * P * 2, self.ref,
                                    self.vr, ca, B=B, S=S, M=M, D=D, L=L, Q=nq, P=P))
             ops.append(GemmOp(ca, pw.w(ca_p + ".output_proj.weight"), rq, d, d, [
