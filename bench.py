@@ -254,8 +254,7 @@ def main():
     gathered = torch.empty(world * a.batch, cfg.num_select, 6, dtype=torch.float32, device=dev) if grouped else None
 
     def step():
-        out = model(images)
-        det = pp.select_packed(out["pred_logits"], out["pred_boxes"], sizes)      # PostProcess -> (B, K, 6) records
+        _out, det = model.detect(images, sizes, pp)       # forward + PostProcess -> (B, K, 6) records
         return ldist.all_gather_detections(det, gathered, always_collective=grouped)
 
     def barrier():
@@ -282,8 +281,7 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for _ in range(a.steps):
-            out = model(images)
-            pp.select_packed(out["pred_logits"], out["pred_boxes"], sizes)
+            model.detect(images, sizes, pp)
         barrier()
         tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

@@ -134,6 +134,19 @@ class LWDETR(nn.Module):
         with torch.cuda.device(plan.dev):
             return plan.run(x, mask, forced_topk=_forced_topk, collect=_collect)
 
+    @torch.no_grad()
+    def detect(self, images, target_sizes, postprocess):
+        """``forward`` + ``postprocess.select_packed`` as one call on a dense batch: returns (output dict, (B, K, 6) f32 records).
+        Same launches and values as the two calls; with launch chains every chain selects its own images on its own stream
+        (the selection is one workgroup per image and would otherwise run alone at the end of the step)."""
+        assert isinstance(images, torch.Tensor) and images.dim() == 4
+        b, _, h, w = images.shape
+        nch = self._chains_for(b)
+        if nch > 1:
+            return self._forward_chains(images, b, h, w, nch, post=(postprocess, target_sizes))
+        out = self.forward(images)
+        return out, postprocess.select_packed(out["pred_logits"], out["pred_boxes"], target_sizes)
+
     @staticmethod
     def _chains_for(b):
         """Launch chains for a dense batch of b images: default two from _TWO_STREAM_MIN_BATCH images; LWDETR_STREAMS / set_streams:
@@ -144,7 +157,7 @@ class LWDETR(nn.Module):
             return _STREAMS if (b % _STREAMS == 0 and b // _STREAMS >= 8) else 1
         return 2 if (b >= _TWO_STREAM_MIN_BATCH and b % 2 == 0) else 1
 
-    def _forward_chains(self, x, b, h, w, nch):
+    def _forward_chains(self, x, b, h, w, nch, post=None):
         """The parts of a dense batch as ``nch`` launch chains on ``nch`` streams. Every kernel of the path runs its workgroups in
         lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b); with other chains a few kernels
         ahead or behind, one part's bandwidth-bound phases and vector-bound attention run beside another part's matrix phases
@@ -159,15 +172,28 @@ class LWDETR(nn.Module):
             while len(self._side_streams) < nch - 1:
                 self._side_streams.append(torch.cuda.Stream(dev))
             outs = plans[0].alloc_outputs(b)        # every chain writes its images' rows of ONE set of output tensors
+            det = None
+            if post is not None:
+                pp, sizes = post
+                sizes = sizes.to(device=dev, dtype=torch.float32).contiguous()
+                det = torch.empty(b, pp.num_select, 6, dtype=torch.float32, device=dev)
+
+            def chain(i):
+                plans[i].run(x[i * part:(i + 1) * part], None, into=(outs, i * part))
+                if post is not None:
+                    sl = slice(i * part, (i + 1) * part)
+                    pp.select_packed(outs[2][-1, sl], outs[3][-1, sl], sizes[sl], out=det[sl])
+
             for i in range(1, nch):
                 side = self._side_streams[i - 1]
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    plans[i].run(x[i * part:(i + 1) * part], None, into=(outs, i * part))
-            plans[0].run(x[:part], None, into=(outs, 0))
+                    chain(i)
+            chain(0)
             for i in range(1, nch):
                 cur.wait_stream(self._side_streams[i - 1])
-            return plans[0].output_dict(*outs)
+            res = plans[0].output_dict(*outs)
+            return res if post is None else (res, det)
 
     @torch.no_grad()
     def capture(self, images, postprocess=None, target_sizes=None):
@@ -235,19 +261,23 @@ class PostProcess(nn.Module):
         xyxy = xyxy * torch.stack([img_w, img_h, img_w, img_h], dim=1)[:, None, :]
         return scores, labels, xyxy
 
-    def select_packed(self, logits, boxes, target_sizes):
+    def select_packed(self, logits, boxes, target_sizes, out=None):
         """``select`` written as ONE (B, K, 6) f32 tensor of rows (score, label, x0, y0, x1, y1) - the record
-        ``lwdetr_amd.dist.all_gather_detections`` ships (same kernel, same values as ``dist.pack_detections(*select(...))``)."""
+        ``lwdetr_amd.dist.all_gather_detections`` ships (same kernel, same values as ``dist.pack_detections(*select(...))``).
+        ``out``: a contiguous (B, K, 6) f32 tensor (or a leading-dimension slice of one) to write into."""
         if not logits.is_cuda:
             from ..dist import pack_detections
-            return pack_detections(*self.select(logits, boxes, target_sizes))
+            res = pack_detections(*self.select(logits, boxes, target_sizes))
+            return res if out is None else out.copy_(res)
         from .. import _native
         b, nq, ncls = logits.shape
         dev = logits.device
         logits = logits.contiguous()
         boxes = boxes.to(logits.dtype).contiguous()
         sizes = target_sizes.to(device=dev, dtype=torch.float32).contiguous()
-        out = torch.empty(b, self.num_select, 6, dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty(b, self.num_select, 6, dtype=torch.float32, device=dev)
+        assert out.shape == (b, self.num_select, 6) and out.dtype == torch.float32 and out.is_contiguous() and out.device == dev
         with torch.cuda.device(dev):
             rc = _native.lib().lwdetr_postprocess_packed(logits.data_ptr(), boxes.data_ptr(), sizes.data_ptr(), b, nq, ncls,
                                                          self.num_select, out.data_ptr(), _native.dtype_code(logits.dtype),

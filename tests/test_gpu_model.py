@@ -194,6 +194,27 @@ def test_full_size_batch_is_consistent_with_the_golden_validated_small_batch_pat
     assert (ffn3["pred_boxes"].float() - forced["pred_boxes"].float()).abs().max().item() < 0.01
 
 
+def test_detect_is_forward_plus_postprocess():
+    """LWDETR.detect = forward + PostProcess.select_packed (with launch chains: every chain selects its own images on its own
+    stream, into one (B, K, 6) tensor) - the same output dict, the same records, bit for bit."""
+    from lwdetr_amd.synth import synth_images, synth_state_dict
+    model, _crit, post = lwdetr_amd.build_model(lwdetr_amd.get_args("small"))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
+    model = model.to(DEV).half().eval()
+    pp = post["bbox"]
+    for b in (32, 4):                                # two launch chains / one
+        x = synth_images(b, 640, 640, seed=21).to(DEV).half()
+        sizes = torch.tensor([[480.0 + 3 * i, 640.0 - 2 * i] for i in range(b)], device=DEV)
+        for _ in range(3):
+            out, det = model.detect(x, sizes, pp)
+            ref = model(x)
+            ref_det = pp.select_packed(ref["pred_logits"], ref["pred_boxes"], sizes)
+            assert det.shape == (b, pp.num_select, 6) and torch.equal(det, ref_det)
+            assert torch.equal(out["pred_logits"], ref["pred_logits"]) and torch.equal(out["pred_boxes"], ref["pred_boxes"])
+            s, l, bx = pp.select(ref["pred_logits"], ref["pred_boxes"], sizes)
+            assert torch.equal(det[..., 0], s) and torch.equal(det[..., 1].long(), l) and torch.equal(det[..., 2:], bx)
+
+
 def test_forward_export_matches_dict_forward():
     """B2: export() / forward_export (reference models/lwdetr.py:103-109, 176-195): tensor in, (coords, logits) out."""
     g = load_golden("tiny_192x256")
