@@ -6,7 +6,10 @@
 #    MFMA busy + wave-cycle split | MFMA instruction counts + GRBM_GUI_ACTIVE | L2 hit / miss
 # 3. tools/pmc_summary.py reduces them to gpurun_out/keep_<tag>/<tag>_pmc_summary.json (HBM bytes per launch, MFMA busy
 #    fraction, wait split per kernel). Copy keep_<tag>/* to profiles/ to publish.
+# All profiled runs use ONE launch chain (LWDETR_STREAMS=1): per-kernel durations and counters of a launch are only meaningful when
+# no other kernel shares its CUs (the un-profiled bench line is the two-chain number).
 set -u
+export LWDETR_STREAMS=1
 TAG=${1:-rX}; shift || true
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
