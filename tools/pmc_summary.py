@@ -24,6 +24,11 @@ def bench_name(k):
         return "mlp_fused"
     if "attn_lds_kernel" in k:
         return "attn_global"
+    if "attn_win_kernel" in k:
+        m = re.search(r"attn_win_kernelI\w+?Li(\d+)E", k)
+        return "attn_window_one_wave_hd%s" % m.group(1) if m else "attn_window_one_wave"
+    if "conv3x3_patch_kernel" in k:
+        return "conv3x3_patch"
     if "attn_kernel" in k:
         m = re.search(r"attn_kernelI\w+?Li(\d+)ELi(\d+)E", k)
         return "attn_kernel_hd%s_qt%s" % (m.group(1), m.group(2)) if m else "attn_kernel"
