@@ -178,3 +178,51 @@ def test_packed_weight_cache_token_sees_every_way_weights_can_change():
     m.train()
     with _pytest.raises(NotImplementedError):
         m._packed_weights()
+
+
+def test_launch_chain_policy():
+    """LWDETR._chains_for / set_streams: default two chains from 32 images (even batches only), 1 = always one, n = n chains
+    whenever the parts have at least 8 images."""
+    from lwdetr_amd.models import lwdetr as L
+    from lwdetr_amd.models.lwdetr import LWDETR
+    try:
+        L.set_streams(0)
+        assert [LWDETR._chains_for(b) for b in (1, 8, 16, 31, 32, 33, 64)] == [1, 1, 1, 1, 2, 1, 2]
+        L.set_streams(1)
+        assert [LWDETR._chains_for(b) for b in (32, 64)] == [1, 1]
+        L.set_streams(4)
+        assert [LWDETR._chains_for(b) for b in (16, 32, 30, 64)] == [1, 4, 1, 4]
+    finally:
+        L.set_streams(0)
+
+
+def test_conv_patch_kernel_index_arithmetic():
+    """Host-side restatement of conv3x3_patch_kernel's integer arithmetic (lw-detr_amd/csrc/gemm.hip): the magic division it uses
+    for pixel coordinates and patch slots, the tap-validity words built from four edge flags, and the linear-patch addressing
+    (tap (dy, dx) of pixel m is patch row (m - m0) + W + 1 + dy W + dx) - against the plain definitions."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for dvs in (17, 25, 40 * 40, 80 * 80, 40, 80, 7, 2, 120 * 120):
+        magic = (1 << 32) // dvs
+        n = np.concatenate([rng.integers(0, 1 << 31, 20000, dtype=np.int64), np.arange(0, 4 * dvs), np.array([(1 << 31) - 1])])
+        q = (n * magic) >> 32
+        r = n - q * dvs
+        q, r = np.where(r >= dvs, q + 1, q), np.where(r >= dvs, r - dvs, r)
+        assert np.array_equal(q, n // dvs) and np.array_equal(r, n % dvs), dvs
+    for h, w in ((40, 40), (10, 13), (7, 9), (2, 2), (1, 5)):
+        for y in range(h):
+            for x in range(w):
+                top, bot, lef, rig = y == 0, y == h - 1, x == 0, x == w - 1
+                row_ok = [0 if top else 7, 7, 0 if bot else 7]
+                col_ok = (0 if lef else 0x49) | 0x92 | (0 if rig else 0x124)
+                vbits = (row_ok[0] | row_ok[1] << 3 | row_ok[2] << 6) & col_ok
+                for tap in range(9):
+                    iy, ix = y + tap // 3 - 1, x + tap % 3 - 1
+                    assert bool((vbits >> tap) & 1) == (0 <= iy < h and 0 <= ix < w), (h, w, y, x, tap)
+    # patch rows: a tile of 128 consecutive pixels starting at m0 keeps global rows m0 - W - 1 .. m0 + 128 + W
+    w_img, m0 = 13, 256
+    for local in (0, 5, 127):
+        for tap in range(9):
+            pr = local + w_img + 1 + (tap // 3 - 1) * w_img + (tap % 3 - 1)
+            assert 0 <= pr < 128 + 2 * w_img + 2
+            assert m0 - w_img - 1 + pr == m0 + local + (tap // 3 - 1) * w_img + (tap % 3 - 1)
