@@ -51,7 +51,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 #define LWDETR_ATTN_ABL 0
 #endif
 
-template <typename T, int HD, int QT>
+template <typename T, int HD, int QT, bool SHORT = false>
 __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
@@ -232,6 +232,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
     // has just issued, one exposed L2 round trip per step.
     // (Short sequences - a 100-key window is 4 steps - keep the conditional form: one wasted fetch per wave costs more
     // there than the drained queue.)
+    if constexpr (SHORT) {
+        // at most 128 keys (window attention at 640 x 640): all four steps' operands are requested before the first one is used -
+        // one memory round trip per wave instead of one per step (the conditional double buffer below drains the queue in front of
+        // every step: 28.9 us per launch at config 2 for 91 MB, 3.1 TB/s)
+        KV f4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_kv(32 * i, f4[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (32 * i >= nkeys) break;
+            step(f4[i], 32 * i);
+        }
+    } else {
     KV fa, fb;
     if (nkeys >= 512) {
         load_kv(0, fa);
@@ -257,6 +270,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const lwdetr_attn_desc p) {
             k0 += 32;
             if (k0 >= nkeys) break;
         }
+    }
     }
 
     // ---- normalise and store: lane holds channels dt*16 + 4g .. +3 of query q0 + t*16 + l15
@@ -844,6 +858,13 @@ int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
     const double bytes = 4.0 * nseq * p.heads * p.keys_per_seq * HD * sizeof(T);
     const int kid = p.kind == 0 ? KID_ATTN_WINDOW : (p.kind == 1 ? KID_ATTN_GLOBAL : KID_ATTN_DECODER);
     ProfScope ps(kid, flops, bytes, st);
+    const char* senv = getenv("LWDETR_ATTN_SHORT");         // 0 = the double-buffered form for every length (A-B runs)
+    if constexpr (QT == 2 && sizeof(T) == 2) {
+        if (p.keys_per_seq <= 128 && !(senv && atoi(senv) == 0)) {
+            hipLaunchKernelGGL((attn_kernel<T, HD, QT, true>), grid, dim3(256), 0, st, p);
+            return lwdetr_check_launch();
+        }
+    }
     hipLaunchKernelGGL((attn_kernel<T, HD, QT>), grid, dim3(256), 0, st, p);
     return lwdetr_check_launch();
 }
