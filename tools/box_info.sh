@@ -9,4 +9,5 @@ p = torch.cuda.get_device_properties(0)
 print("device:", p.name, "CUs", p.multi_processor_count, "mem GB", round(p.total_memory / 2**30), "clock MHz", getattr(p, "clock_rate", 0) // 1000)
 PY
 ./tools/ubench/mfma_peak 2>/dev/null | head -6
+./tools/ubench/whole_cu 2>/dev/null
 python tools/vitblock_bench.py 2>&1 | grep -v amdgpu | head -8
