@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const lwdetr_gemm_de
     constexpr int B_MY = BN / 16 / 4;                       // weight pieces (16 rows x 64 B) per wave and stage
     constexpr int WN = BN / 2, TM = 2, TN = WN / 32, NRD = TM + TN;       // fragment reads per 16-deep chunk
     typedef typename Vec<T>::v8 V8;
-    static_assert(sizeof(T) == 2 && BN % 64 == 0 && CIN % KB == 0, "16-bit, whole pieces");
+    static_assert(sizeof(T) == 2 && BN % 64 == 0 && CIN % KB == 0 && (NCH == 4 || NCH == 6), "16-bit, whole pieces, 4 or 6 stages per tap");
     extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
     T* patch = (T*)conv_smem;
     T* ring = patch + (long)np_patch * 512;                 // np_patch pieces of 1 KB
