@@ -8,6 +8,7 @@ import torch
 p = torch.cuda.get_device_properties(0)
 print("device:", p.name, "CUs", p.multi_processor_count, "mem GB", round(p.total_memory / 2**30), "clock MHz", getattr(p, "clock_rate", 0) // 1000)
 PY
+for u in mfma_peak whole_cu; do [ -x tools/ubench/$u ] || hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/$u 2>/dev/null; done
 ./tools/ubench/mfma_peak 2>/dev/null | head -6
 ./tools/ubench/whole_cu 2>/dev/null
 python tools/vitblock_bench.py 2>&1 | grep -v amdgpu | head -8
