@@ -1338,12 +1338,8 @@ int try_launch_conv_patch(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken
             d.lda % 8 != 0 || d.a_col0 % 8 != 0 || ((size_t)d.A & 15) != 0 || ((size_t)d.W & 15) != 0 || hw <= 1 || d.M % hw != 0 ||
             d.conv_wout < 2 || (long)(d.M + 256) * d.lda >= (1L << 30))       // 32-bit element offsets into A
             return LWDETR_OK;
-        const char* nenv = getenv("LWDETR_CONV_PATCH_NST");       // tuning: ring depth
-        const int nst = nenv ? atoi(nenv) : 3;
-        int rc;
-        if (d.N == 128) rc = nst == 4 ? launch_conv_patch<T, 128, 4>(d, st) : nst == 6 ? launch_conv_patch<T, 128, 6>(d, st) :
-                             nst == 8 ? launch_conv_patch<T, 128, 8>(d, st) : launch_conv_patch<T, 128, 3>(d, st);
-        else rc = launch_conv_patch<T, 192, 3>(d, st);
+        // ring depth 3 (two workgroups per CU at N = 128); 4 / 6 / 8 measured no faster (profiles/r3e_conv3x3_patch.txt)
+        const int rc = d.N == 128 ? launch_conv_patch<T, 128, 3>(d, st) : launch_conv_patch<T, 192, 3>(d, st);
         taken = rc != LWDETR_ERR_UNSUPPORTED;
         return taken ? rc : LWDETR_OK;
     }
