@@ -192,6 +192,10 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     unsigned long long tt_wait = 0, tt_bar = 0;
 #endif
     auto boundary = [&](int a, int b, int extra) {
+        // nothing of the step before may be scheduled behind this point: the MFMAs that consume the fragments of the pieces below
+        // `a` - and with them the lgkmcnt wait for those reads - stay in front of the barrier that frees their ring slots (hipcc
+        // does not see the DMA; gemm.hip's convolution kernel shows what happens otherwise)
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef LWDETR_VB_TIMING
         const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
 #endif
