@@ -154,7 +154,31 @@ class ForwardPlan:
         self.debug = {}
         self.buffers = []            # every tensor the plan's kernels write (tests/test_gpu_chains.py restores / compares them)
         self._own = lambda t: (self.buffers.append(t), t)[1]
-        self._z = lambda *s, dt=None: self._own(torch.zeros(*s, dtype=dt or T, device=dev))
+        # LWDETR_ARENA=1 carves the work buffers out of a few large allocations (256 MB chunks) instead of ~200 separate ones -
+        # an experiment for the boxes on which the model process alone runs slow (profiles/r3f_box_spread.txt: suspected page
+        # placement); on the usual boxes it measures the same or 0.5 % slower (12.50 vs 12.57 k img/s), so it is off by default.
+        self._arena, self._arena_off = None, 0
+        use_arena = os.environ.get("LWDETR_ARENA", "0") == "1"
+
+        def zeros(*s, dt=None):
+            dt = dt or T
+            if len(s) == 1 and isinstance(s[0], (tuple, list)):
+                s = tuple(s[0])
+            n = 1
+            for v in s:
+                n *= int(v)
+            nbytes = n * torch.empty(0, dtype=dt).element_size()
+            if not use_arena or nbytes == 0:
+                return self._own(torch.zeros(*s, dtype=dt, device=dev))
+            chunk = 256 << 20
+            need = (nbytes + 255) // 256 * 256
+            if self._arena is None or self._arena_off + need > self._arena.numel():
+                self._arena, self._arena_off = torch.empty(max(chunk, need), dtype=torch.uint8, device=dev), 0
+            t = self._arena[self._arena_off:self._arena_off + nbytes].view(dt).view(*s)
+            self._arena_off += need
+            return self._own(t.zero_())
+
+        self._z = zeros
         self._build_vit()
         self._build_projector()
         self._build_transformer()
