@@ -12,7 +12,11 @@ import os
 import sys
 import time
 
-import torch
+# dmabuf IPC: the ROCm host driver of this pool does not support the legacy IPC mode; RCCL's peer-to-peer setup over xGMI
+# (hipIpcGetMemHandle) needs this BEFORE the HSA runtime starts, i.e. before the first device call (see lwdetr_amd.dist)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -202,7 +206,7 @@ def self_launch(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"self-launch: {' '.join(cmd[1:8])} ...")
-    raise SystemExit(subprocess.call(cmd))
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ)))      # HSA_ENABLE_IPC_MODE_LEGACY=0 travels with it
 
 
 def launch_check(rank, world):
@@ -299,8 +303,10 @@ def main():
                                f"{a.dtype}, random-init weights (synthetic COCO-shaped input)",
                    "global_batch": world * a.batch, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                    "collective": "all_gather_into_tensor of (B,K,6) f32 detections" if grouped else "none", "backend": backend,
-                   "launch_chains": 2 if (a.batch >= 32 and a.batch % 2 == 0 and os.environ.get("LWDETR_STREAMS", "0") != "1") else 1},
+                   "launch_chains": type(model)._chains_for(a.batch)},
     }
+    if rank == 0 and backend == "nccl":
+        result["config"]["rccl"] = ldist.rccl_report()      # RCCL version + the transports of the channels rank 0 connected
     if dt_nog is not None:
         result["ms_per_step_without_all_gather"] = round(dt_nog / a.steps * 1e3, 3)
     gf = GFLOP_PER_IMAGE.get((a.size, a.res))
@@ -314,6 +320,7 @@ def main():
         # while the other chain shares the chip says nothing about the kernel, so this pass runs ONE chain: per-kernel figures
         # (and the rocprofv3 summaries under profiles/) are those of the full-batch launches on their own
         from lwdetr_amd.models import lwdetr as _lw
+        streams_before = _lw._STREAMS
         _lw.set_streams(1)
         step()
         torch.cuda.synchronize(dev)
@@ -323,7 +330,7 @@ def main():
         torch.cuda.synchronize(dev)
         prof = _native.prof_collect()
         _native.prof_enable(False)
-        _lw.set_streams(0)
+        _lw.set_streams(streams_before)
         tot = sum(v["ms"] for v in prof.values())
         table = {k: {"ms_per_step": round(v["ms"] / 3, 4), "launches_per_step": v["count"] // 3,
                      "share": round(v["ms"] / tot, 4)} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}

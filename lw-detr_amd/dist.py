@@ -6,11 +6,24 @@ pickle -> ByteTensor -> padded ``all_gather`` -> unpickle of per-image results (
 ``datasets/coco_eval.py:181-200``) - with a single ``all_gather_into_tensor`` of a ``(B/W, K, 6)`` f32 tensor
 (score, label, x0, y0, x1, y1; labels < 2^24 are exact in f32). No other collective is on the data path.
 """
+import glob
 import os
+import re
 import sys
+import tempfile
 
-import torch
-import torch.distributed as dist
+# The ROCm host driver of the MI355X pool supports dmabuf IPC only: RCCL's intra-node peer-to-peer setup over xGMI
+# (hipIpcGetMemHandle / hipIpcOpenMemHandle between the ranks of a node) fails with "invalid argument" in the legacy IPC mode.
+# The HSA runtime reads this when it starts (the first device call of the process), so it is set on import - before torch has
+# touched the GPU in any process that imports lwdetr_amd.dist first (bench.py sets it before `import torch` as well) - and never
+# over a value the caller chose. init_from_env() warns when the runtime was already up without it.
+_IPC_ENV_PRESET = "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+_RCCL_LOG = None        # NCCL_DEBUG_FILE pattern of this job when init_from_env switched the RCCL init log on
 
 
 def init_from_env(backend=None, single_node=None, force=None):
@@ -40,10 +53,50 @@ def init_from_env(backend=None, single_node=None, force=None):
                 if k not in os.environ:
                     os.environ[k] = v
                     print(f"[lwdetr_amd.dist] single-node job: {k}={v}", file=sys.stderr, flush=True)
+        if not _IPC_ENV_PRESET and torch.cuda.is_initialized():
+            print("[lwdetr_amd.dist] warning: the GPU runtime was initialised before lwdetr_amd.dist was imported and "
+                  "HSA_ENABLE_IPC_MODE_LEGACY was not exported; export HSA_ENABLE_IPC_MODE_LEGACY=0 for multi-rank RCCL on "
+                  "this driver (dmabuf IPC only)", file=sys.stderr, flush=True)
+        if "NCCL_DEBUG" not in os.environ:
+            # RCCL's init log (version, topology, the transport of every channel) into a per-process file: rccl_report() reads
+            # rank 0's copy after the run so that the bench line can show "P2P over xGMI only". INFO logs at init / connect only.
+            global _RCCL_LOG
+            _RCCL_LOG = os.path.join(tempfile.gettempdir(), f"lwdetr_rccl_{os.environ.get('MASTER_PORT', '0')}")
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,P2P,SHM,NET")
+            os.environ["NCCL_DEBUG_FILE"] = _RCCL_LOG + ".%p.log"
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def parse_rccl_log(text):
+    """RCCL / NCCL INFO log -> {"version", "channels_p2p", "channels_shm", "channels_net", "xgmi_only"}: the `... via P2P/IPC`
+    (xGMI / PCIe peer access), `via SHM` (host memory bounce) and `via NET` (sockets / IB) channel lines of the connect phase."""
+    ver = re.search(r"(?:RCCL|NCCL) version ([0-9][^\s]*)", text)
+    p2p = len(re.findall(r"via P2P/", text))
+    shm = len(re.findall(r"via SHM", text))
+    net = len(re.findall(r"via NET/", text))
+    return {"version": ver.group(1) if ver else None, "channels_p2p": p2p, "channels_shm": shm, "channels_net": net,
+            "xgmi_only": bool(p2p) and not shm and not net}
+
+
+def rccl_report():
+    """What this process's RCCL saw (bench.py prints it for N > 1): library version as torch reports it, and - when init_from_env
+    switched the init log on - the transports of the channels this rank connected."""
+    rep = {"torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.cuda.is_available() else None,
+           "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "NCCL_P2P_DISABLE")}}
+    if _RCCL_LOG:
+        text = ""
+        for fp in glob.glob(_RCCL_LOG + f".{os.getpid()}.log"):
+            try:
+                text += open(fp, errors="replace").read()
+            except OSError:
+                pass
+        rep.update(parse_rccl_log(text))
+        rep["log"] = "NCCL_DEBUG=INFO init log of rank 0" if text else "no RCCL log found"
+    return rep
 
 
 def shard_range(total: int, rank: int, world: int):

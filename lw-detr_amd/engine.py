@@ -649,7 +649,7 @@ class ForwardPlan:
                 self.op_rowmax(stream)
             collect.update({"topk_idx": self.topk_idx.clone(), "enc.class_max": self.cls_max.clone(), "memory": self.memory.view(B, S, d).clone(),
                             "taps_cat": self.taps_cat.clone(), "x": self.x.clone(), "hs": self.hs.clone(),
-                            "om": self.om.view(B, S, d).clone()})
+                            "om": self.om.view(B, S, d).clone(), "launch_chains": 1})
         return out
 
     def alloc_outputs(self, total):

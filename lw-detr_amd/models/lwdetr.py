@@ -57,11 +57,12 @@ class LWDETR(nn.Module):
         self._packed = None      # PackedWeights for the current (device, dtype, parameter versions)
         self._plans = {}         # (B, H, W) -> ForwardPlan
         self._tok_tensors = None
-        self._side_streams = []
+        self._side_streams = {}  # device -> side streams of the launch chains (a stream belongs to one device)
 
     # ---- cache invalidation: any change of device / dtype / parameter values drops the packed weights
     def invalidate_cache(self):
         self._packed, self._plans, self._tok_tensors = None, {}, None
+        self._side_streams = {}
 
     def _apply(self, fn, *a, **k):
         self.invalidate_cache()
@@ -106,11 +107,16 @@ class LWDETR(nn.Module):
         if private:
             with torch.cuda.device(tok[0]):
                 return ForwardPlan(pw, b, h, w)
-        if key not in self._plans:
-            if len(self._plans) >= 4:
-                self._plans.pop(next(iter(self._plans)))
-            with torch.cuda.device(tok[0]):
-                self._plans[key] = ForwardPlan(pw, b, h, w)
+        if key in self._plans:
+            self._plans[key] = self._plans.pop(key)          # LRU: most recently used last
+            return self._plans[key]
+        # room for 4 batch shapes, each with all of its launch chains (a shape's chains are evicted together, oldest shape first)
+        shapes = list(dict.fromkeys(k[:3] for k in self._plans))
+        if key[:3] not in shapes and len(shapes) >= 4:
+            for k in [k for k in self._plans if k[:3] == shapes[0]]:
+                self._plans.pop(k)
+        with torch.cuda.device(tok[0]):
+            self._plans[key] = ForwardPlan(pw, b, h, w)
         return self._plans[key]
 
     @torch.no_grad()
@@ -127,9 +133,9 @@ class LWDETR(nn.Module):
                     samples.mask = None
             x, mask = samples.tensors, samples.mask
         b, _, h, w = x.shape
-        nch = self._chains_for(b) if (mask is None and _forced_topk is None and _collect is None and isinstance(samples, torch.Tensor)) else 1
+        nch = self._chains_for(b) if (mask is None and _forced_topk is None and isinstance(samples, torch.Tensor)) else 1
         if nch > 1:
-            return self._forward_chains(x, b, h, w, nch)
+            return self._forward_chains(x, b, h, w, nch, collect=_collect)
         plan = self._plan(b, h, w)
         with torch.cuda.device(plan.dev):
             return plan.run(x, mask, forced_topk=_forced_topk, collect=_collect)
@@ -157,7 +163,7 @@ class LWDETR(nn.Module):
             return _STREAMS if (b % _STREAMS == 0 and b // _STREAMS >= 8) else 1
         return 2 if (b >= _TWO_STREAM_MIN_BATCH and b % 2 == 0) else 1
 
-    def _forward_chains(self, x, b, h, w, nch, post=None):
+    def _forward_chains(self, x, b, h, w, nch, post=None, collect=None):
         """The parts of a dense batch as ``nch`` launch chains on ``nch`` streams. Every kernel of the path runs its workgroups in
         lockstep (all of them load, then all compute, then all store - DESIGN.md section 5b); with other chains a few kernels
         ahead or behind, one part's bandwidth-bound phases and vector-bound attention run beside another part's matrix phases
@@ -169,8 +175,10 @@ class LWDETR(nn.Module):
         dev = plans[0].dev
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
-            while len(self._side_streams) < nch - 1:
-                self._side_streams.append(torch.cuda.Stream(dev))
+            sides = self._side_streams.setdefault(dev, [])
+            while len(sides) < nch - 1:
+                sides.append(torch.cuda.Stream(dev))
+            assert all(s_.device == dev for s_ in sides[:nch - 1])
             outs = plans[0].alloc_outputs(b)        # every chain writes its images' rows of ONE set of output tensors
             det = None
             if post is not None:
@@ -185,13 +193,20 @@ class LWDETR(nn.Module):
                     pp.select_packed(outs[2][-1, sl], outs[3][-1, sl], sizes[sl], out=det[sl])
 
             for i in range(1, nch):
-                side = self._side_streams[i - 1]
+                side = sides[i - 1]
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     chain(i)
             chain(0)
             for i in range(1, nch):
-                cur.wait_stream(self._side_streams[i - 1])
+                cur.wait_stream(sides[i - 1])
+            if collect is not None:      # tests: the chains' intermediate buffers, concatenated to what one full-batch plan holds
+                S, d = plans[0].S, plans[0].d
+                cat = lambda f, dim=0: torch.cat([f(p) for p in plans], dim)
+                collect.update({"topk_idx": cat(lambda p: p.topk_idx), "enc.class_max": cat(lambda p: p.cls_max),
+                                "memory": cat(lambda p: p.memory.view(part, S, d)), "taps_cat": cat(lambda p: p.taps_cat),
+                                "x": cat(lambda p: p.x), "hs": cat(lambda p: p.hs, 1), "om": cat(lambda p: p.om.view(part, S, d)),
+                                "launch_chains": nch})
             res = plans[0].output_dict(*outs)
             return res if post is None else (res, det)
 

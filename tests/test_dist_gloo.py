@@ -162,6 +162,31 @@ def test_bench_self_launches_its_ranks():
     assert line == {"launch_check": True, "n_gpus": 2, "backend": "gloo"}
 
 
+@_retry_rendezvous
+def test_bench_self_launches_eight_ranks():
+    """The driver's scaling run goes to N = 8: the same launch path with eight ranks (gloo, CPU), every rank's shard present in
+    the gathered tensor in rank order, and the IPC mode the RCCL ranks need exported to the children."""
+    rc, line, err = _run_bench(["--gpus", "8", "--launch-check"], env_extra={"OMP_NUM_THREADS": "1"}, timeout=400)
+    assert rc == 0, err[-2000:]
+    assert line == {"launch_check": True, "n_gpus": 8, "backend": "gloo"}
+
+
+def test_ipc_mode_is_exported_before_the_gpu_runtime_starts():
+    """bench.py and lwdetr_amd.dist export HSA_ENABLE_IPC_MODE_LEGACY=0 on import (dmabuf IPC: the only mode this driver has;
+    RCCL's xGMI peer-to-peer setup fails without it) and never override a caller's value."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    code = "import sys; sys.path.insert(0, %r); import os; import lwdetr_amd.dist; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "0"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "1"
+    from lwdetr_amd import dist as D
+    rep = D.parse_rccl_log("h:1:1 [0] NCCL INFO RCCL version 2.26.6-HEAD:x\nh:1:2 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\n"
+                           "h:1:2 [0] NCCL INFO Channel 01/0 : 0[0] -> 7[7] via P2P/IPC\n")
+    assert rep["version"].startswith("2.26.6") and rep["channels_p2p"] == 2 and rep["xgmi_only"]
+    assert not D.parse_rccl_log("NCCL INFO Channel 00/0 : 0[0] -> 1[1] via SHM/direct/direct")["xgmi_only"]
+
+
 def test_bench_refuses_world_size_mismatch():
     """Under a launcher that started 2 ranks, `--gpus 4` must not produce a line (it used to report n_gpus of a
     different job size silently)."""

@@ -29,8 +29,11 @@ def _two_plans(size, batch, res, dtype, seed=3):
     return model, x, model._plans[(part, res, res, 0)], model._plans[(part, res, res, 1)]
 
 
-@pytest.mark.parametrize("size,batch,res,dtype", [("small", 32, 640, torch.float16), ("medium", 16, 640, torch.bfloat16),
-                                                  ("large", 16, 640, torch.float16)])
+# BASELINE batches (configs 2, 3 and the per-GPU shard of 4): the kernel selection depends on the row count (large-tile GEMM from
+# 16 384 rows, patch-resident convolution from 100 workgroups, one-wave window attention), so the chains are stressed at the
+# benchmarked sizes, not at smaller stand-ins
+@pytest.mark.parametrize("size,batch,res,dtype", [("small", 32, 640, torch.float16), ("medium", 64, 640, torch.bfloat16),
+                                                  ("large", 32, 640, torch.float16)])
 def test_every_launch_repeats_bit_for_bit_beside_the_other_chain(size, batch, res, dtype):
     model, x, p0, p1 = _two_plans(size, batch, res, dtype)
     part = batch // 2

@@ -23,7 +23,7 @@ def _free_port():
 
 def _torchrun(args, timeout=600):
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)      # bench.py / lwdetr_amd.dist set it themselves (dmabuf IPC)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
@@ -51,5 +51,8 @@ def test_bench_under_torchrun_one_rank_initialises_rccl():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["config"].get("backend") == "nccl", d["config"]
+    rccl = d["config"].get("rccl")
+    assert rccl and rccl["torch_nccl_version"] and rccl["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0", rccl
+    assert rccl.get("version"), rccl          # parsed from RCCL's own init log (one rank: no channels to connect)
     with open(os.path.join(ROOT, "gpurun_out", "bench_torchrun_one_rank.json"), "w") as f:
         f.write(json.dumps(d) + "\n")

@@ -298,24 +298,27 @@ def test_hip_graph_is_isolated_from_eager_calls_of_the_same_shape():
     assert (r2["pred_logits"] - p_logits).abs().max().item() > 1e-3                        # padding does change the result
 
 
-def test_two_launch_chains_equal_two_half_batches():
+@pytest.mark.parametrize("size,batch,dtype", [("small", 32, torch.float16), ("medium", 64, torch.bfloat16), ("large", 32, torch.float16)])
+def test_two_launch_chains_equal_two_half_batches(size, batch, dtype):
     """Dense batches of >= 32 images run as two launch chains on two streams (LWDETR._forward_chains): the result is, bit for
     bit, what the model returns for the two half batches one after the other, and within 16-bit noise of the one-chain batch
     (whose GEMM tiles differ with the row count)."""
     import lwdetr_amd
     from lwdetr_amd.models import lwdetr as L
     from lwdetr_amd.synth import synth_images, synth_state_dict
-    model, _, post = lwdetr_amd.build_model(lwdetr_amd.get_args("small"))
+    model, _, post = lwdetr_amd.build_model(lwdetr_amd.get_args(size))
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
-    model = model.to("cuda:0").half().eval()
-    x = synth_images(32, 640, 640, seed=11).to("cuda:0").half()
+    model = model.to("cuda:0").to(dtype).eval()
+    x = synth_images(batch, 640, 640, seed=11).to("cuda:0").to(dtype)
+    half = batch // 2
     try:
         L.set_streams(0)
+        assert type(model)._chains_for(batch) == 2
         twos = [model(x) for _ in range(24)]          # repeated: kernels of the two chains share CUs in a different way every time
         two = twos[0]
         torch.cuda.synchronize()
         L.set_streams(1)
-        lo, hi, one = model(x[:16]), model(x[16:]), model(x)
+        lo, hi, one = model(x[:half]), model(x[half:]), model(x)
         torch.cuda.synchronize()
     finally:
         L.set_streams(0)
@@ -328,6 +331,6 @@ def test_two_launch_chains_equal_two_half_batches():
     assert len(two["aux_outputs"]) == len(one["aux_outputs"]) and two["aux_outputs"][0]["pred_logits"].shape == one["aux_outputs"][0]["pred_logits"].shape
     same_sel = (two["enc_outputs"]["pred_boxes"] == one["enc_outputs"]["pred_boxes"]).all(-1).all(-1)        # images whose selection did not reorder
     assert same_sel.float().mean().item() > 0.5
-    assert (two["pred_logits"][same_sel].float() - one["pred_logits"][same_sel].float()).abs().max().item() < 0.1
-    res = post["bbox"](two, torch.tensor([[480.0, 640.0]] * 32, device="cuda:0"))
-    assert len(res) == 32 and res[31]["boxes"].shape[-1] == 4
+    assert (two["pred_logits"][same_sel].float() - one["pred_logits"][same_sel].float()).abs().max().item() < (0.1 if dtype == torch.float16 else 0.8)
+    res = post["bbox"](two, torch.tensor([[480.0, 640.0]] * batch, device="cuda:0"))
+    assert len(res) == batch and res[batch - 1]["boxes"].shape[-1] == 4
