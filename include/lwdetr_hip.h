@@ -201,6 +201,25 @@ int lwdetr_vit_block(void* x, long ldx, const void* att, long ldatt, const void*
                      long ld2, float* stats_out, long M, int C, float eps, float eps_next, int has_qkv, void* q_out,
                      void* k_out, void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream);
 
+/* ---- row-local chains of Linear stages in one launch (round 4; 16-bit dtypes) ------------------------------------------
+ * lwdetr_enc_chain: everything the forward does to ALL S encoder tokens between the projector's C2f block and the two-stage
+ * top-k, one launch: [k5 != 0: C2f.cv2 1x1 convolution (BatchNorm folded) + SiLU + channel LayerNorm -> `memory`
+ * (models/backbone/projector.py:117-132, :21-47)] -> value_proj of all `nl` decoder layers with the padding mask on the OUTPUT
+ * rows (models/ops/modules/ms_deform_attn.py:110-114) -> enc_output Linear on the rows with invalid proposals zeroed +
+ * enc_output_norm -> output_memory `om` (models/transformer.py:113-116, :231) -> enc_out_class_embed -> class logits `cls`
+ * (row stride ld_cls >= 96, columns >= ncls are zero weight pads) and their row maximum `cls_max` (f32; :244-246).
+ * in: k5 != 0: (M, ld_in) rows holding the k5 = 5 * d / 2 channels of the C2f concat of one level, image b = row / npix,
+ * destination row b * S + lsi + row % npix of the (total_rows, D) tensors; k5 == 0: `memory` rows themselves (npix = S, lsi = 0).
+ * wstream / vec: lwdetr_amd.kernels.pack_enc_chain (4 KB pieces of 32 output channels x 64 k-slots in MFMA lane order, consumption
+ * order cv2 | values | enc_output | class, + 2 zero pieces; f32 vectors [b2 | ln_w | ln_b] | b_enc | g_enc | be_enc | b_cls[96] | b_val);
+ * sizes from the helpers. D in {256, 384}; k5 in {0, 640 (D = 256)}. */
+long lwdetr_enc_chain_vec_floats(int D, int k5);
+long lwdetr_enc_chain_pieces(int D, int k5, int nl);
+int lwdetr_enc_chain(const void* in, long ld_in, int k5, void* memory, void* om, void* cls, long ld_cls, float* cls_max,
+                     void* const* values, int nl, const unsigned char* rowvalid, const unsigned char* notpad,
+                     const void* wstream, const float* vec, long M, int D, int npix, int S, int lsi, long total_rows,
+                     int ncls, float eps_p, float eps_e, int dtype, void* hip_stream);
+
 /* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
  * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */
 int lwdetr_select_gather(const void* om, const void* enc_cls, long ldc, const float* props, const int64_t* idx,

@@ -1,0 +1,403 @@
+// Row-local chains of Linear (+ activation / LayerNorm / row max) stages in ONE launch, for gfx950, 16-bit types (round 4).
+//
+// The LW-DETR forward has several runs of small GEMMs that never mix rows: the projector's last 1x1 convolution + LayerNorm, the
+// two-stage head over all S encoder tokens (enc_output Linear -> LayerNorm -> class Linear -> row max; transformer.py:231-246), the
+// value projections of every decoder layer (ms_deform_attn.py:110-114), the decoder's output projections + LayerNorms, the
+// box / class heads. As separate launches each is a latency-bound 64 x 64 ring GEMM (0.21 of the HBM roofline, MFMA busy 0.06,
+// profiles/r3_*) that writes its (rows x 256) activation to HBM for the next one to read back. Here a wave owns 32 rows for the whole
+// chain, exactly as in vitblock.hip:
+//   * D[channel][row] = W * x^T on 32x32x16 MFMAs: the weights are the A operand, the wave's rows the B operand, held in registers
+//     as k-runs of 8; an accumulator tile handed on as the next B operand needs no data movement (its k-slot order is baked into
+//     the packed weights, lwdetr_amd/kernels.py:chain_kslots); LayerNorm of a row = in-lane sums + one half-wave exchange;
+//   * all weights of the chain are ONE stream of 4 KB pieces (32 output channels x 64 k-slots = 4 MFMA fragments of 1 KB in lane
+//     order), DMA'd linearly through an LDS ring shared by the 4 waves of the workgroup (counted s_waitcnt vmcnt + one raw barrier
+//     per output tile), fragment reads are base + lane * 16 (+ wrapped piece offset): conflict-free, no swizzle.
+// Rounding points are those of the unfused launches (every stage output is rounded to the storage type before it is used again).
+#include "common.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+template <typename T> struct Mma32c;
+template <> struct Mma32c<f16> {
+    static __device__ __forceinline__ f32x16 k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma32c<bf16> {
+    static __device__ __forceinline__ f32x16 k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
+typedef float cf32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 cf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct CPk;
+template <> struct CPk<f16> { typedef cf16x2 v2; };
+template <> struct CPk<bf16> { typedef cbf16x2 v2; };
+template <typename T> __device__ __forceinline__ unsigned cpack2(float a, float b) {
+    const cf32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, typename CPk<T>::v2));
+}
+template <typename T> __device__ __forceinline__ void cunpack2(unsigned w, float& a, float& b) {
+    const typename CPk<T>::v2 v = __builtin_bit_cast(typename CPk<T>::v2, w);
+    a = to_f32<T>(v[0]); b = to_f32<T>(v[1]);
+}
+// accumulator registers 8 jb .. 8 jb + 7 of lane (j, h) = rows 16 jb + 4 h + {0..3} and 16 jb + 8 + 4 h + {0..3} of column j, as
+// four packed pairs; after the half-wave exchange every lane holds 8 CONSECUTIVE rows 16 jb + 8 h .. + 7 (one 16-byte store)
+__device__ __forceinline__ cu32x4 crows8(unsigned a0, unsigned a1, unsigned b0, unsigned b1) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    return cu32x4{s0[0], s1[0], s0[1], s1[1]};
+}
+
+#define CH_VMW(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+__device__ __forceinline__ void ch_wait_le(int n) {       // at most n vector-memory operations of this wave outstanding (n wave-uniform)
+    if (n >= 63) { CH_VMW(63); return; }
+    switch (n) {
+#define CH_C(N) case N: CH_VMW(N); break;
+        CH_C(0) CH_C(1) CH_C(2) CH_C(3) CH_C(4) CH_C(5) CH_C(6) CH_C(7) CH_C(8) CH_C(9) CH_C(10) CH_C(11) CH_C(12) CH_C(13) CH_C(14) CH_C(15)
+        CH_C(16) CH_C(17) CH_C(18) CH_C(19) CH_C(20) CH_C(21) CH_C(22) CH_C(23) CH_C(24) CH_C(25) CH_C(26) CH_C(27) CH_C(28) CH_C(29) CH_C(30)
+        CH_C(31) CH_C(32) CH_C(33) CH_C(34) CH_C(35) CH_C(36) CH_C(37) CH_C(38) CH_C(39) CH_C(40) CH_C(41) CH_C(42) CH_C(43) CH_C(44) CH_C(45)
+        CH_C(46) CH_C(47) CH_C(48) CH_C(49) CH_C(50) CH_C(51) CH_C(52) CH_C(53) CH_C(54) CH_C(55) CH_C(56) CH_C(57) CH_C(58) CH_C(59) CH_C(60)
+        CH_C(61) CH_C(62)
+#undef CH_C
+        default: CH_VMW(0); break;
+    }
+}
+
+constexpr int CH_PIECE_B = 4096;          // 32 output channels x 64 k-slots: 4 fragments
+constexpr int CH_RD = 8;                  // fragment read-ahead (registers); the host appends 2 zero pieces so that it may run past the end
+
+// The weight stream of one workgroup: ring of NSLOT pieces in LDS, every wave DMAs fragment `wave` of every piece.
+template <int NSLOT>
+struct WRing {
+    const char* src; unsigned lds0; int np; int issued; int wave; unsigned lane16;
+    __device__ __forceinline__ void dma1k(const char* src_uniform, unsigned voff, unsigned lds_dst) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)src_uniform);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)src_uniform >> 32));
+        const char* sp = (const char*)(((uintptr_t)hi << 32) | lo);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(sp) : "memory");
+    }
+    __device__ __forceinline__ void dma_piece(int piece) {
+        const unsigned slot = (unsigned)piece % NSLOT;
+        dma1k(src + (size_t)piece * CH_PIECE_B, (unsigned)wave * 1024u + lane16, lds0 + slot * CH_PIECE_B + (unsigned)wave * 1024u);
+    }
+    __device__ __forceinline__ void fill() { for (; issued < NSLOT && issued < np; ++issued) dma_piece(issued); }
+    // The tile that starts at piece a and spans n pieces: pieces below a + n + 2 have landed (the fragment read-ahead runs CH_RD = 8
+    // fragments = 2 pieces ahead), every wave is done with the pieces below a, and their slots are refilled.
+    __device__ __forceinline__ void begin_tile(int a, int n) {
+        __builtin_amdgcn_sched_barrier(0);
+        int b = a + n + 2; b = b < np ? b : np;
+        ch_wait_le(issued - b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the slots that are about to be freed
+        __builtin_amdgcn_s_barrier();
+        int lim = a + NSLOT; lim = lim < np ? lim : np;
+        while (issued < lim) { dma_piece(issued); ++issued; }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+struct EncParams {
+    const void* in; long ld_in;           // PF: the C2f concat (M, ld_in), K5 channels; else `memory` rows (M, D)
+    void* memory;                         // (B * S, D): written when PF
+    void* om; void* cls; long ld_cls; float* cls_max;
+    void* values[6]; int nl;
+    const unsigned char* rowvalid; const unsigned char* notpad;
+    const void* wstream; const float* vec; int np;
+    long M;                               // input rows of this launch
+    int npix, S, lsi;                     // input row m -> image b = m / npix, memory row b * S + lsi + m % npix
+    int ncls;
+    float eps_p, eps_e;
+    unsigned mem_bytes, cls_bytes, in_bytes;
+};
+
+// One wave's 32 rows through: [PF: cv2 (K5 -> D) + SiLU + LayerNorm2d -> memory] -> value projections of all decoder layers ->
+// enc_output Linear + LayerNorm -> output_memory -> class Linear -> class logits + their row maximum.
+template <typename T, int D, bool PF, int K5>
+__global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
+    typedef typename Vec<T>::v8 V8;
+    constexpr int KS = D / 16, NTI = D / 32, PPT = D / 64;
+    constexpr int KSI = PF ? K5 / 16 : KS, PPT5 = K5 / 64;
+    constexpr int NSLOT = 32;
+    constexpr int NCT = 3;                          // class tiles (ncls <= 96)
+    constexpr int VEC_F = (PF ? 3 * D : 0) + 3 * D + 32 * NCT + 6 * D;
+    constexpr int VEC_B = (VEC_F * 4 + 4095) / 4096 * 4096, VEC_DPW = VEC_B / 4096;
+    static_assert(KS % CH_RD == 0 && KSI % CH_RD == 0, "the fragment read-ahead ring must divide every tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float* vec = (const float*)(smem + NSLOT * CH_PIECE_B);
+    const float* b2s = vec; const float* gps = vec + D; const float* bps = vec + 2 * D;
+    const float* bes = vec + (PF ? 3 * D : 0); const float* ges = bes + D; const float* bts = ges + D;
+    const float* bcs = bts + D; const float* bvs = bcs + 32 * NCT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+
+    const long t0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long mrow = t0 + j;
+    const bool live = mrow < p.M;
+    // memory-space row of this lane's token
+    const long img = live ? mrow / p.npix : 0;
+    const long mm = live ? img * p.S + p.lsi + (mrow - img * p.npix) : 0;
+
+    // ---- input rows first (they are older than every weight DMA: nothing queues behind the ring fill), then vectors + ring
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const unsigned in_off = live ? (unsigned)(mrow * p.ld_in * 2) : 0x80000000u;
+    V8 xin[KSI];
+#pragma unroll
+    for (int t = 0; t < KSI; ++t)
+        xin[t] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(r_in, in_off + (unsigned)((16 * t + 8 * h) * 2), 0, 0));
+    const unsigned char rv = live ? p.rowvalid[mm] : 0, npd = live ? p.notpad[mm] : 0;
+
+    WRing<NSLOT> ring;
+    ring.src = (const char*)p.wstream; ring.lds0 = lds0; ring.np = p.np; ring.issued = 0; ring.wave = wave; ring.lane16 = lane16;
+    {
+        const char* vsrc = (const char*)p.vec;
+#pragma unroll
+        for (int i = 0; i < VEC_DPW; ++i) {
+            const unsigned kb = (unsigned)(wave * VEC_DPW + i) * 1024u;
+            ring.dma1k(vsrc, kb + lane16, lds0 + NSLOT * CH_PIECE_B + kb);
+        }
+        ring.fill();
+    }
+    auto frag = [&](int g) -> V8 {           // global fragment index g = 4 * piece + fragment
+        return *(const V8*)(smem + (((unsigned)g & (NSLOT * 4 - 1)) << 10) + lane16);
+    };
+    auto bias16 = [&](const float* src) -> f32x16 {      // src[8 b + 4 h + e] -> register 4 b + e
+        f32x16 r;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 v = *(const f32x4*)(src + 8 * b + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[4 * b + e] = v[e];
+        }
+        return r;
+    };
+    const __amdgpu_buffer_rsrc_t r_mem = __builtin_amdgcn_make_buffer_rsrc(p.memory ? p.memory : p.om, 0, p.memory ? (int)p.mem_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_om = __builtin_amdgcn_make_buffer_rsrc(p.om, 0, (int)p.mem_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_cls = __builtin_amdgcn_make_buffer_rsrc(p.cls, 0, (int)p.cls_bytes, 0x00020000);
+    const unsigned row_off = live ? (unsigned)(mm * D * 2) : 0x80000000u;           // byte offset of the row in (B * S, D) tensors
+    const unsigned cls_off = live ? (unsigned)(mm * p.ld_cls * 2) : 0x80000000u;
+
+    int pc = 0;                                  // next piece
+    V8 fr[CH_RD];
+    // 32 channels x 32 rows: nf fragments against x[0 .. nf), fragment stream position 4 * pc
+    auto tile = [&](auto& x, auto nf_tag, f32x16 acc) -> f32x16 {
+        constexpr int nf = decltype(nf_tag)::value;
+        const int g0 = 4 * pc;
+#pragma unroll
+        for (int f = 0; f < nf; ++f) {
+            const V8 a = fr[f % CH_RD];
+            fr[f % CH_RD] = frag(g0 + f + CH_RD);
+            acc = Mma32c<T>::k16(a, x[f], acc);
+        }
+        pc += nf / 4;
+        return acc;
+    };
+    // rows rounded to T held as packed pairs (dword d of tile n = registers 2 d, 2 d + 1): LayerNorm with affine, stores the
+    // result to `rs` rows (16-byte pieces) and leaves it as B operands in xo (k-slot order of an accumulator hand-over)
+    auto layernorm_store = [&](unsigned (&xp)[NTI][8], float s, const float* gam, const float* bet, float eps,
+                               const __amdgpu_buffer_rsrc_t& rs, V8 (&xo)[KS]) {
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n)
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                float v0, v1; cunpack2<T>(xp[n][d], v0, v1);
+                v0 -= mean; v1 -= mean;
+                v = fmaf(v0, v0, v); v = fmaf(v1, v1, v);
+            }
+        v += __shfl_xor(v, 32);
+        const float rstd = 1.f / sqrtf(v * (1.f / D) + eps);
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+            unsigned w[8];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c0 = 32 * n + 8 * b + 4 * h;
+                const f32x4 g = *(const f32x4*)(gam + c0), be = *(const f32x4*)(bet + c0);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    float v0, v1; cunpack2<T>(xp[n][2 * b + d], v0, v1);
+                    w[2 * b + d] = cpack2<T>(fmaf((v0 - mean) * rstd, g[2 * d], be[2 * d]), fmaf((v1 - mean) * rstd, g[2 * d + 1], be[2 * d + 1]));
+                }
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const cu32x4 ow = crows8(w[4 * jb], w[4 * jb + 1], w[4 * jb + 2], w[4 * jb + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(ow, rs, row_off + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+            }
+            xo[2 * n] = __builtin_bit_cast(V8, cu32x4{w[0], w[1], w[2], w[3]});
+            xo[2 * n + 1] = __builtin_bit_cast(V8, cu32x4{w[4], w[5], w[6], w[7]});
+        }
+    };
+
+    V8 xf[KS];                                   // `memory` rows as B operands
+    // first tile: its pieces (and the two read ahead) have landed; the read-ahead ring starts
+    ring.begin_tile(0, PF ? PPT5 : PPT);
+#pragma unroll
+    for (int i = 0; i < CH_RD; ++i) fr[i] = frag(i);
+    if constexpr (PF) {
+        // ---- projector: C2f.cv2 (1x1 conv, BatchNorm folded) + SiLU, LayerNorm over channels -> memory (projector.py:117-132)
+        unsigned xp[NTI][8];
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+            if (n > 0) ring.begin_tile(pc, PPT5);
+            const f32x16 acc = tile(xin, std::integral_constant<int, KSI>{}, bias16(b2s + 32 * n));
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const float a0 = acc[2 * d], a1 = acc[2 * d + 1];
+                const unsigned w = cpack2<T>(a0 / (1.f + __expf(-a0)), a1 / (1.f + __expf(-a1)));
+                xp[n][d] = w;
+                float v0, v1; cunpack2<T>(w, v0, v1);
+                s += v0 + v1;
+            }
+        }
+        layernorm_store(xp, s, gps, bps, p.eps_p, r_mem, xf);
+    } else {
+#pragma unroll
+        for (int t = 0; t < KS; ++t) xf[t] = xin[t];
+    }
+    // ---- value projections of all decoder layers (ms_deform_attn.py:110-114: masked_fill of the OUTPUT rows of padded pixels)
+    {
+        const int nvt = p.nl * NTI;
+#pragma unroll 1
+        for (int vt = 0; vt < nvt; ++vt) {
+            if (PF || vt > 0) ring.begin_tile(pc, PPT);
+            f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bvs + 32 * vt));
+            const int li = vt / NTI, n = vt - li * NTI;
+            const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(p.values[li], 0, (int)p.mem_bytes, 0x00020000);
+            if (!npd) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const cu32x4 ow = crows8(cpack2<T>(acc[8 * jb], acc[8 * jb + 1]), cpack2<T>(acc[8 * jb + 2], acc[8 * jb + 3]),
+                                         cpack2<T>(acc[8 * jb + 4], acc[8 * jb + 5]), cpack2<T>(acc[8 * jb + 6], acc[8 * jb + 7]));
+                __builtin_amdgcn_raw_buffer_store_b128(ow, r_v, row_off + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+            }
+        }
+    }
+    // ---- enc_output Linear on the rows (invalid proposals: the INPUT row is zeroed, transformer.py:113-116) + LayerNorm -> output_memory
+    {
+        if (!rv) {
+#pragma unroll
+            for (int t = 0; t < KS; ++t) xf[t] = V8{};
+        }
+        unsigned xp[NTI][8];
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+            ring.begin_tile(pc, PPT);
+            const f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bes + 32 * n));
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const unsigned w = cpack2<T>(acc[2 * d], acc[2 * d + 1]);
+                xp[n][d] = w;
+                float v0, v1; cunpack2<T>(w, v0, v1);
+                s += v0 + v1;
+            }
+        }
+        layernorm_store(xp, s, ges, bts, p.eps_e, r_om, xf);
+    }
+    // ---- class logits of every token and their maximum (the two-stage selection score, transformer.py:244-246)
+    {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < NCT; ++n) {
+            ring.begin_tile(pc, PPT);
+            const f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bcs + 32 * n));
+            unsigned w[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                w[d] = cpack2<T>(acc[2 * d], acc[2 * d + 1]);
+                float v0, v1; cunpack2<T>(w[d], v0, v1);
+                const int c = 32 * n + 8 * (d >> 1) + 4 * h + 2 * (d & 1);
+                if (c < p.ncls) mx = fmaxf(mx, v0);
+                if (c + 1 < p.ncls) mx = fmaxf(mx, v1);
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const cu32x4 ow = crows8(w[4 * jb], w[4 * jb + 1], w[4 * jb + 2], w[4 * jb + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(ow, r_cls, cls_off + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (live && h == 0) p.cls_max[mm] = mx;
+    }
+}
+
+template <typename T, int D, bool PF, int K5>
+int launch_enc(const EncParams& p, hipStream_t st) {
+    constexpr int NSLOT = 32, NCT = 3;
+    constexpr int VEC_F = (PF ? 3 * D : 0) + 3 * D + 32 * NCT + 6 * D;
+    constexpr int VEC_B = (VEC_F * 4 + 4095) / 4096 * 4096;
+    constexpr size_t lds = (size_t)NSLOT * CH_PIECE_B + VEC_B;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)enc_chain_kernel<T, D, PF, K5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done[dev] = true;
+    }
+    const long grid = (p.M + 127) / 128;
+    const double kin = PF ? (double)K5 : 0.0;
+    ProfScope ps(KID_CHAIN, 2.0 * p.M * D * (kin + D + 32.0 * NCT + (double)p.nl * D),
+                 (double)p.M * 2.0 * ((PF ? K5 + D : D) + D + 96.0 + (double)p.nl * D) + 4.0 * p.M, st);
+    hipLaunchKernelGGL((enc_chain_kernel<T, D, PF, K5>), dim3((unsigned)grid), dim3(256), lds, st, p);
+    return lwdetr_check_launch();
+}
+
+template <typename T>
+int dispatch_enc(const EncParams& p, int D, int k5, hipStream_t st) {
+    if (D == 256 && k5 == 640) return launch_enc<T, 256, true, 640>(p, st);
+    if (D == 256 && k5 == 0) return launch_enc<T, 256, false, 640>(p, st);
+    if (D == 384 && k5 == 0) return launch_enc<T, 384, false, 960>(p, st);
+    return LWDETR_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" long lwdetr_enc_chain_vec_floats(int D, int k5) {
+    const long f = (k5 ? 3L * D : 0) + 3L * D + 96 + 6L * D;
+    return (f * 4 + 4095) / 4096 * 4096 / 4;
+}
+extern "C" long lwdetr_enc_chain_pieces(int D, int k5, int nl) {
+    return (k5 ? (long)(D / 32) * (k5 / 64) : 0) + (long)(nl * (D / 32) + D / 32 + 3) * (D / 64) + 2;
+}
+
+extern "C" int lwdetr_enc_chain(const void* in, long ld_in, int k5, void* memory, void* om, void* cls, long ld_cls, float* cls_max,
+                                void* const* values, int nl, const unsigned char* rowvalid, const unsigned char* notpad,
+                                const void* wstream, const float* vec, long M, int D, int npix, int S, int lsi, long total_rows,
+                                int ncls, float eps_p, float eps_e, int dtype, void* hip_stream) {
+    if (!in || !om || !cls || !cls_max || !values || !rowvalid || !notpad || !wstream || !vec || M < 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    if (nl < 1 || nl > 6 || ncls < 1 || ncls > 96 || ld_cls < 96 || ld_cls % 8 != 0 || ld_in % 8 != 0 || npix <= 0 || S < npix || lsi < 0) return LWDETR_ERR_BAD_ARG;
+    if (k5 && !memory) return LWDETR_ERR_BAD_ARG;
+    if (((uintptr_t)in | (uintptr_t)om | (uintptr_t)cls | (uintptr_t)memory | (uintptr_t)wstream | (uintptr_t)vec) % 16 != 0) return LWDETR_ERR_BAD_ARG;
+    if ((double)total_rows * (D > ld_cls ? D : ld_cls) * 2.0 >= 2147483000.0 || (double)M * ld_in * 2.0 >= 2147483000.0) return LWDETR_ERR_UNSUPPORTED;
+    EncParams p = {};
+    p.in = in; p.ld_in = ld_in; p.memory = k5 ? memory : nullptr; p.om = om; p.cls = cls; p.ld_cls = ld_cls; p.cls_max = cls_max;
+    for (int i = 0; i < nl; ++i) {
+        if (!values[i] || (uintptr_t)values[i] % 16 != 0) return LWDETR_ERR_BAD_ARG;
+        p.values[i] = values[i];
+    }
+    p.nl = nl; p.rowvalid = rowvalid; p.notpad = notpad; p.wstream = wstream; p.vec = vec;
+    p.np = (int)lwdetr_enc_chain_pieces(D, k5, nl);
+    p.M = M; p.npix = npix; p.S = S; p.lsi = lsi; p.ncls = ncls; p.eps_p = eps_p; p.eps_e = eps_e;
+    p.mem_bytes = (unsigned)((unsigned long)total_rows * D * 2ul);
+    p.cls_bytes = (unsigned)((unsigned long)total_rows * ld_cls * 2ul);
+    p.in_bytes = (unsigned)((unsigned long)M * ld_in * 2ul);
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (dtype) {
+        case DT_F16: return dispatch_enc<f16>(p, D, k5, st);
+        case DT_BF16: return dispatch_enc<bf16>(p, D, k5, st);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}

@@ -143,7 +143,7 @@ __device__ __forceinline__ long tok_encode(int b, int y, int x, const TokLayout&
 // ---- profiling hooks (prof.hip): per-kernel HIP-event timing on the launch stream, off by default.
 enum {
     KID_MSDA = 0, KID_MSDA_GENERIC, KID_MSDA_FUSED, KID_GEMM, KID_GEMM_CONV, KID_GEMM_PATCH, KID_ATTN_WINDOW,
-    KID_ATTN_GLOBAL, KID_ATTN_DECODER, KID_LAYERNORM, KID_ELTWISE, KID_MLP, KID_VITBLOCK, KID_COUNT
+    KID_ATTN_GLOBAL, KID_ATTN_DECODER, KID_LAYERNORM, KID_ELTWISE, KID_MLP, KID_VITBLOCK, KID_CHAIN, KID_COUNT
 };
 void lwdetr_prof_begin(int kid, double flops, double bytes, hipStream_t s);
 void lwdetr_prof_end(hipStream_t s);

@@ -13,7 +13,7 @@ std::vector<Rec> g_done;
 bool g_on = false;
 const char* kNames[KID_COUNT] = {
     "msda_forward_vec8", "msda_forward_generic", "msda_fused_forward", "gemm_mfma", "gemm_mfma_conv3x3",
-    "gemm_mfma_patch", "attn_window", "attn_global", "attn_decoder", "layernorm_rows", "eltwise", "mlp_fused", "vit_block"};
+    "gemm_mfma_patch", "attn_window", "attn_global", "attn_decoder", "layernorm_rows", "eltwise", "mlp_fused", "vit_block", "row_chain"};
 }  // namespace
 
 void lwdetr_prof_begin(int kid, double flops, double bytes, hipStream_t s) {

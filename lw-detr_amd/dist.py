@@ -87,6 +87,8 @@ def rccl_report():
     switched the init log on - the transports of the channels this rank connected."""
     rep = {"torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.cuda.is_available() else None,
            "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "NCCL_P2P_DISABLE")}}
+    if not _RCCL_LOG:
+        rep["log"] = f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG')} was set by the caller: RCCL's init log is where the caller sent it"
     if _RCCL_LOG:
         text = ""
         for fp in glob.glob(_RCCL_LOG + f".{os.getpid()}.log"):

@@ -53,6 +53,7 @@ def test_bench_under_torchrun_one_rank_initialises_rccl():
     assert d["config"].get("backend") == "nccl", d["config"]
     rccl = d["config"].get("rccl")
     assert rccl and rccl["torch_nccl_version"] and rccl["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0", rccl
-    assert rccl.get("version"), rccl          # parsed from RCCL's own init log (one rank: no channels to connect)
+    # RCCL's own init log is parsed unless the box's environment already routes NCCL_DEBUG somewhere (then the report says so)
+    assert rccl.get("version") or "set by the caller" in rccl.get("log", ""), rccl
     with open(os.path.join(ROOT, "gpurun_out", "bench_torchrun_one_rank.json"), "w") as f:
         f.write(json.dumps(d) + "\n")

@@ -177,6 +177,16 @@ def main():
         "nop2_after_cndmask": ("s_nop 1 behind every v_cndmask_b32", dict(nop_after=r"v_cndmask_b32", nops=2)),
         "nop8_before_pk": ("s_nop 7 in front of every packed-f32 instruction", dict(nop_before=r"v_pk_(fma|mul|add)_f32", nops=8)),
     }
+    loc_idx = [k for k, (_, c) in enumerate(pk) if c == "loc"]
+    for n_, k_ in enumerate(loc_idx):
+        txt = " ".join(lines[pk[k_][0]].split(";")[0].split())
+        variants[f"only_loc{n_:02d}"] = (f"ONLY this instruction packed, all others scalar: {txt}", dict(scalar=lambda k, c, l, k_=k_: k != k_))
+    crossed = [k for k in loc_idx if "op_sel:" in lines[pk[k][0]]]
+    sgpr = [k for k in loc_idx if re.search(r"\bs\[\d+:\d+\]", lines[pk[k][0]].split(";")[0])]
+    variants["only_crossed"] = (f"only the {len(crossed)} packed instructions with a crossed op_sel (a half reads the OTHER register of a pair) packed", dict(scalar=lambda k, c, l: k not in crossed))
+    variants["only_sgpr"] = (f"only the {len(sgpr)} packed instructions with an SGPR-pair source packed", dict(scalar=lambda k, c, l: k not in sgpr))
+    variants["loc_but_crossed"] = ("location arithmetic packed except the crossed-op_sel instructions, accumulation packed", dict(scalar=lambda k, c, l: k in crossed))
+    variants["loc_but_sgpr"] = ("location arithmetic packed except the SGPR-pair instructions, accumulation packed", dict(scalar=lambda k, c, l: k in sgpr))
     meta = {"kernel": KERNEL, "packed_total": len(pk), "packed_loc": n_loc, "packed_acc": n_acc, "acc_fed_by_previous_cvt": len(b2b), "variants": {}}
     for name, (desc, kw) in variants.items():
         src = os.path.join(OUT, name + ".s")
