@@ -88,6 +88,11 @@ def lib():
         l.lwdetr_vit_block_stream_bytes.restype = C.c_long
         l.lwdetr_vit_block_vec_floats.argtypes = [i]
         l.lwdetr_vit_block_vec_floats.restype = C.c_long
+        l.lwdetr_enc_chain.argtypes = [vp, lg, i, vp, vp, vp, lg, vp, vp, i, vp, vp, vp, vp, lg, i, i, i, i, lg, i, f, f, i, vp]
+        l.lwdetr_enc_chain_vec_floats.argtypes = [i, i]
+        l.lwdetr_enc_chain_vec_floats.restype = C.c_long
+        l.lwdetr_enc_chain_pieces.argtypes = [i, i, i]
+        l.lwdetr_enc_chain_pieces.restype = C.c_long
         l.lwdetr_select_gather.argtypes = [vp, vp, lg, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         l.lwdetr_decoder_inputs.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
         l.lwdetr_box_reparam.argtypes = [vp, vp, lg, vp, lg, i, vp]

@@ -50,15 +50,13 @@ __device__ __forceinline__ cu32x4 crows8(unsigned a0, unsigned a1, unsigned b0, 
 }
 
 #define CH_VMW(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-__device__ __forceinline__ void ch_wait_le(int n) {       // at most n vector-memory operations of this wave outstanding (n wave-uniform)
-    if (n >= 63) { CH_VMW(63); return; }
+// at most n vector-memory operations of this wave outstanding (n wave-uniform, 0 <= n <= 31: the ring never holds more pieces)
+__device__ __forceinline__ void ch_wait_le(int n) {
     switch (n) {
 #define CH_C(N) case N: CH_VMW(N); break;
-        CH_C(0) CH_C(1) CH_C(2) CH_C(3) CH_C(4) CH_C(5) CH_C(6) CH_C(7) CH_C(8) CH_C(9) CH_C(10) CH_C(11) CH_C(12) CH_C(13) CH_C(14) CH_C(15)
+        CH_C(1) CH_C(2) CH_C(3) CH_C(4) CH_C(5) CH_C(6) CH_C(7) CH_C(8) CH_C(9) CH_C(10) CH_C(11) CH_C(12) CH_C(13) CH_C(14) CH_C(15)
         CH_C(16) CH_C(17) CH_C(18) CH_C(19) CH_C(20) CH_C(21) CH_C(22) CH_C(23) CH_C(24) CH_C(25) CH_C(26) CH_C(27) CH_C(28) CH_C(29) CH_C(30)
-        CH_C(31) CH_C(32) CH_C(33) CH_C(34) CH_C(35) CH_C(36) CH_C(37) CH_C(38) CH_C(39) CH_C(40) CH_C(41) CH_C(42) CH_C(43) CH_C(44) CH_C(45)
-        CH_C(46) CH_C(47) CH_C(48) CH_C(49) CH_C(50) CH_C(51) CH_C(52) CH_C(53) CH_C(54) CH_C(55) CH_C(56) CH_C(57) CH_C(58) CH_C(59) CH_C(60)
-        CH_C(61) CH_C(62)
+        CH_C(31)
 #undef CH_C
         default: CH_VMW(0); break;
     }
@@ -82,13 +80,18 @@ struct WRing {
         const unsigned slot = (unsigned)piece % NSLOT;
         dma1k(src + (size_t)piece * CH_PIECE_B, (unsigned)wave * 1024u + lane16, lds0 + slot * CH_PIECE_B + (unsigned)wave * 1024u);
     }
-    __device__ __forceinline__ void fill() { for (; issued < NSLOT && issued < np; ++issued) dma_piece(issued); }
+    __device__ __forceinline__ void fill(int first) { for (; issued < first && issued < NSLOT && issued < np; ++issued) dma_piece(issued); }
     // The tile that starts at piece a and spans n pieces: pieces below a + n + 2 have landed (the fragment read-ahead runs CH_RD = 8
     // fragments = 2 pieces ahead), every wave is done with the pieces below a, and their slots are refilled.
+    // STEADY: the wait count while the ring is being topped up (NSLOT - pieces of the tile before - n - 2), one s_waitcnt without
+    // the branch tree of the general case (which only the first and the last tiles of the stream take)
+    template <int STEADY>
     __device__ __forceinline__ void begin_tile(int a, int n) {
         __builtin_amdgcn_sched_barrier(0);
         int b = a + n + 2; b = b < np ? b : np;
-        ch_wait_le(issued - b);
+        const int v = issued - b;
+        if (v == STEADY) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(STEADY) : "memory");
+        else ch_wait_le(v);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the slots that are about to be freed
         __builtin_amdgcn_s_barrier();
         int lim = a + NSLOT; lim = lim < np ? lim : np;
@@ -159,8 +162,14 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
             const unsigned kb = (unsigned)(wave * VEC_DPW + i) * 1024u;
             ring.dma1k(vsrc, kb + lane16, lds0 + NSLOT * CH_PIECE_B + kb);
         }
-        ring.fill();
+        // only the pieces of the first tile (+ read-ahead + a few) now: the first begin_tile tops the ring up. The compiler waits for
+        // the input rows with a vmcnt that does not know of the DMAs: every DMA issued before that wait would have to land first.
+        ring.fill((PF ? PPT5 : PPT) + 2 + 4);
     }
+    // fake uses: hipcc places its own wait for the input rows and flags HERE, before the ring fill of the first begin_tile
+#pragma unroll
+    for (int t = 0; t < KSI; ++t) asm volatile("" :: "v"(xin[t]));
+    asm volatile("" :: "v"((int)rv), "v"((int)npd));
     auto frag = [&](int g) -> V8 {           // global fragment index g = 4 * piece + fragment
         return *(const V8*)(smem + (((unsigned)g & (NSLOT * 4 - 1)) << 10) + lane16);
     };
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
 
     V8 xf[KS];                                   // `memory` rows as B operands
     // first tile: its pieces (and the two read ahead) have landed; the read-ahead ring starts
-    ring.begin_tile(0, PF ? PPT5 : PPT);
+    ring.template begin_tile<4>(0, PF ? PPT5 : PPT);
 #pragma unroll
     for (int i = 0; i < CH_RD; ++i) fr[i] = frag(i);
     if constexpr (PF) {
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         float s = 0.f;
 #pragma unroll
         for (int n = 0; n < NTI; ++n) {
-            if (n > 0) ring.begin_tile(pc, PPT5);
+            if (n > 0) ring.template begin_tile<NSLOT - 2 * PPT5 - 2>(pc, PPT5);
             const f32x16 acc = tile(xin, std::integral_constant<int, KSI>{}, bias16(b2s + 32 * n));
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         const int nvt = p.nl * NTI;
 #pragma unroll 1
         for (int vt = 0; vt < nvt; ++vt) {
-            if (PF || vt > 0) ring.begin_tile(pc, PPT);
+            if (PF || vt > 0) ring.template begin_tile<NSLOT - 2 * PPT - 2>(pc, PPT);
             f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bvs + 32 * vt));
             const int li = vt / NTI, n = vt - li * NTI;
             const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(p.values[li], 0, (int)p.mem_bytes, 0x00020000);
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         float s = 0.f;
 #pragma unroll
         for (int n = 0; n < NTI; ++n) {
-            ring.begin_tile(pc, PPT);
+            ring.template begin_tile<NSLOT - 2 * PPT - 2>(pc, PPT);
             const f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bes + 32 * n));
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         float mx = -INFINITY;
 #pragma unroll
         for (int n = 0; n < NCT; ++n) {
-            ring.begin_tile(pc, PPT);
+            ring.template begin_tile<NSLOT - 2 * PPT - 2>(pc, PPT);
             const f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bcs + 32 * n));
             unsigned w[8];
 #pragma unroll

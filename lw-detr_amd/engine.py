@@ -69,19 +69,23 @@ class PackedWeights:
         return self._cache[ck]
 
     # ---- conv + eval-BatchNorm folding (reference ConvX: conv(bias=False) -> BN -> act, projector.py:85-98)
+    def convx_f32(self, prefix):
+        """BatchNorm-folded conv weight (Cout, ky*kx*Cin) and bias, f32 masters on the parameters' device."""
+        w = self.sd[prefix + ".conv.weight"].detach().float()
+        g = self.sd[prefix + ".bn.weight"].detach().float()
+        b = self.sd[prefix + ".bn.bias"].detach().float()
+        mu = self.sd[prefix + ".bn.running_mean"].detach().float()
+        var = self.sd[prefix + ".bn.running_var"].detach().float()
+        s = g / torch.sqrt(var + 1e-5)
+        w = w * s[:, None, None, None]
+        return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), b - mu * s      # k = tap*Cin + ci
+
     def convx(self, prefix):
         ck = ("convx", prefix)
         if ck not in self._cache:
-            w = self.sd[prefix + ".conv.weight"].detach().float()
-            g = self.sd[prefix + ".bn.weight"].detach().float()
-            b = self.sd[prefix + ".bn.bias"].detach().float()
-            mu = self.sd[prefix + ".bn.running_mean"].detach().float()
-            var = self.sd[prefix + ".bn.running_var"].detach().float()
-            s = g / torch.sqrt(var + 1e-5)
-            w = w * s[:, None, None, None]
-            wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)         # (Cout, ky*kx*Cin): k = tap*Cin + ci
+            wk, bk = self.convx_f32(prefix)
             self._cache[ck] = (wk.to(device=self.device, dtype=self.dtype).contiguous(),
-                               (b - mu * s).to(device=self.device, dtype=torch.float32).contiguous())
+                               bk.to(device=self.device, dtype=torch.float32).contiguous())
         return self._cache[ck]
 
 
@@ -287,6 +291,10 @@ class ForwardPlan:
         pre = "backbone.0.projector"
         self.memory = z(B * self.S, d)
         self.level_feats = []
+        # round 4: everything between the C2f block and the two-stage top-k as ONE launch (lwdetr_enc_chain, built in
+        # _build_transformer); with one level and d = 256 the chain also takes the projector's cv2 + LayerNorm in front
+        self.use_chain = K.enc_chain_supported(d, self.T, ncls=pw.sd["class_embed.weight"].shape[0], nl=cfg.dec_layers, rows=B * self.S)
+        self.chain_front = None
         for li, name in enumerate(cfg.projector_scale):
             scale = LEVEL_SCALE[name]
             hl, wl = self.level_hw[li]
@@ -346,6 +354,9 @@ class ForwardPlan:
                 ops.append(GemmOp(tmp, wb, M, c, 9 * c, [seg(dst, 0, c, ldo=5 * c, bias=bb, act=ACT_SILU)], lda=c,
                                   a_mode=A_CONV3x3, a_tok=ras, conv_cin=c, conv_stride=1, a_col0=0, conv_hout=hl,
                                   conv_wout=wl, keep=(dst,)))
+            if self.use_chain and self.L == 1 and K.enc_chain_supported(d, self.T, k5=5 * c) and os.environ.get("LWDETR_CHAIN_FRONT", "1") != "0":
+                self.chain_front = dict(ycat=ycat, k5=5 * c, cv2=st + ".cv2", ln=f"{pre}.stages.{li}.1", npix=npix, lsi=self.lsi[li], M=M)
+                continue
             w2, b2 = pw.convx(st + ".cv2")
             zf = z(M, d)
             ops.append(GemmOp(ycat, w2, M, d, 5 * c, [seg(zf, 0, d, ldo=d, bias=b2, act=ACT_SILU)]))
@@ -364,32 +375,62 @@ class ForwardPlan:
         # ---- encoder-side (all S tokens): enc_output Linear+LN, class logits; value_proj of all decoder layers
         self.rowvalid = self._own(torch.ones(B * S, dtype=torch.uint8, device=dev))
         self.notpad = self._own(torch.ones(B * S, dtype=torch.uint8, device=dev))
-        e1, self.om = z(B * S, d), z(B * S, d)
+        self.om = z(B * S, d)
         self.ncls = pw.sd["class_embed.weight"].shape[0]
         self.ldc = _ceil4(self.ncls)
-        self.enc_cls = z(B * S, self.ldc)
-        ops = self.ops_enc
-        ops.append(GemmOp(self.memory, pw.w(f"{t}.enc_output.0.weight"), B * S, d, d, [
-            seg(e1, 0, d, ldo=d, bias=pw.f(f"{t}.enc_output.0.bias"), rowmask=self.rowvalid)]))
-        ops.append(LayerNormOp(e1, pw.f(f"{t}.enc_output_norm.0.weight"), pw.f(f"{t}.enc_output_norm.0.bias"),
-                               self.om, B * S, d, 1e-5))
-        ops.append(GemmOp(self.om, pw.w(f"{t}.enc_out_class_embed.0.weight"), B * S, self.ncls, d, [
-            seg(self.enc_cls, 0, self.ncls, ldo=self.ldc, bias=pw.f(f"{t}.enc_out_class_embed.0.bias"))]))
         nl = cfg.dec_layers
-        wv = pw.custom("value_proj_all.w", lambda: torch.cat(
-            [pw.sd[f"{t}.decoder.layers.{i}.cross_attn.value_proj.weight"].detach().float() for i in range(nl)], 0))
-        bv = pw.custom("value_proj_all.b", lambda: torch.cat(
-            [pw.sd[f"{t}.decoder.layers.{i}.cross_attn.value_proj.bias"].detach().float() for i in range(nl)], 0),
-            dtype=torch.float32)
-        self.values = [z(B * S, d) for _ in range(nl)]
-        vsegs = [seg(self.values[i], i * d, (i + 1) * d, ldo=d, bias=bv[i * d:], rowmask=self.notpad, rowmask_after=True)
-                 for i in range(nl)]
-        for g0 in range(0, nl, 3):
-            grp = vsegs[g0:g0 + 3]
-            for s_ in grp:
-                s_.n_begin -= g0 * d
-                s_.n_end -= g0 * d
-            ops.append(GemmOp(self.memory, wv[g0 * d:], B * S, len(grp) * d, d, grp, keep=(wv, bv)))
+        self.ldc_enc = 96 if self.use_chain else self.ldc
+        self.enc_cls = z(B * S, self.ldc_enc)
+        self.cls_max = self._own(torch.zeros(B, S, dtype=torch.float32, device=dev))
+        ops = self.ops_enc
+        if self.use_chain:
+            self.values = [z(B * S, d) for _ in range(nl)]
+            fr = self.chain_front
+            sdv = pw.sd
+
+            def build():
+                cv2 = None
+                if fr is not None:
+                    w2, b2 = pw.convx_f32(fr["cv2"])
+                    cv2 = (w2, b2, sdv[fr["ln"] + ".weight"], sdv[fr["ln"] + ".bias"])
+                return K.pack_enc_chain(
+                    d, self.T, sdv[f"{t}.enc_output.0.weight"], sdv[f"{t}.enc_output.0.bias"], sdv[f"{t}.enc_output_norm.0.weight"],
+                    sdv[f"{t}.enc_output_norm.0.bias"], sdv[f"{t}.enc_out_class_embed.0.weight"], sdv[f"{t}.enc_out_class_embed.0.bias"],
+                    torch.cat([sdv[f"{t}.decoder.layers.{i}.cross_attn.value_proj.weight"].detach().float() for i in range(nl)], 0),
+                    torch.cat([sdv[f"{t}.decoder.layers.{i}.cross_attn.value_proj.bias"].detach().float() for i in range(nl)], 0), cv2=cv2)
+
+            stream_w, vec = pw.custom_multi(f"{t}.enc_chain.packed.{'front' if fr else 'plain'}", build)
+            if fr is not None:
+                ops.append(K.EncChainOp(fr["ycat"], fr["k5"], fr["k5"], self.memory, self.om, self.enc_cls, self.ldc_enc, self.cls_max,
+                                        self.values, self.rowvalid, self.notpad, stream_w, vec, M=fr["M"], d=d, npix=fr["npix"], S=S,
+                                        lsi=fr["lsi"], total_rows=B * S, ncls=self.ncls, eps_p=1e-6, eps_e=1e-5))
+            else:
+                ops.append(K.EncChainOp(self.memory, d, 0, None, self.om, self.enc_cls, self.ldc_enc, self.cls_max, self.values,
+                                        self.rowvalid, self.notpad, stream_w, vec, M=B * S, d=d, npix=S, S=S, lsi=0, total_rows=B * S,
+                                        ncls=self.ncls, eps_p=1e-6, eps_e=1e-5))
+        else:
+            e1 = z(B * S, d)
+            ops.append(GemmOp(self.memory, pw.w(f"{t}.enc_output.0.weight"), B * S, d, d, [
+                seg(e1, 0, d, ldo=d, bias=pw.f(f"{t}.enc_output.0.bias"), rowmask=self.rowvalid)]))
+            ops.append(LayerNormOp(e1, pw.f(f"{t}.enc_output_norm.0.weight"), pw.f(f"{t}.enc_output_norm.0.bias"),
+                                   self.om, B * S, d, 1e-5))
+            ops.append(GemmOp(self.om, pw.w(f"{t}.enc_out_class_embed.0.weight"), B * S, self.ncls, d, [
+                seg(self.enc_cls, 0, self.ncls, ldo=self.ldc, bias=pw.f(f"{t}.enc_out_class_embed.0.bias"))]))
+        if not self.use_chain:
+            wv = pw.custom("value_proj_all.w", lambda: torch.cat(
+                [pw.sd[f"{t}.decoder.layers.{i}.cross_attn.value_proj.weight"].detach().float() for i in range(nl)], 0))
+            bv = pw.custom("value_proj_all.b", lambda: torch.cat(
+                [pw.sd[f"{t}.decoder.layers.{i}.cross_attn.value_proj.bias"].detach().float() for i in range(nl)], 0),
+                dtype=torch.float32)
+            self.values = [z(B * S, d) for _ in range(nl)]
+            vsegs = [seg(self.values[i], i * d, (i + 1) * d, ldo=d, bias=bv[i * d:], rowmask=self.notpad, rowmask_after=True)
+                     for i in range(nl)]
+            for g0 in range(0, nl, 3):
+                grp = vsegs[g0:g0 + 3]
+                for s_ in grp:
+                    s_.n_begin -= g0 * d
+                    s_.n_end -= g0 * d
+                ops.append(GemmOp(self.memory, wv[g0 * d:], B * S, len(grp) * d, d, grp, keep=(wv, bv)))
         # ---- selected queries: bbox MLP of the two-stage head on the nq gathered rows only (row-wise op)
         self.om_sel = z(B * nq, d)
         s1, s2 = z(B * nq, d), z(B * nq, d)
@@ -532,10 +573,10 @@ class ForwardPlan:
         self.dim_t = (10000 ** (2 * (dim_t // 2) / (d // 2))).contiguous()          # transformer.py:46-47
         ptr = lambda t_: t_.data_ptr()
         self.op_gather = K.RawOp("lwdetr_select_gather", (
-            ptr(self.om), ptr(self.enc_cls), self.ldc, ptr(self.props), ptr(self.topk_idx), ptr(self.om_sel),
+            ptr(self.om), ptr(self.enc_cls), self.ldc_enc, ptr(self.props), ptr(self.topk_idx), ptr(self.om_sel),
             ptr(self.enc_logits_sel), ptr(self.props_sel), B, S, d, nq, self.ncls, code), keep=())
-        self.cls_max = f32(B, S)
-        self.op_rowmax = K.RawOp("lwdetr_rowmax", (ptr(self.enc_cls), self.ldc, B * S, self.ncls, ptr(self.cls_max), code), keep=())
+        # (with the chain kernel the class maxima are already written; the launch below then only serves forced selections' collect)
+        self.op_rowmax = K.RawOp("lwdetr_rowmax", (ptr(self.enc_cls), self.ldc_enc, B * S, self.ncls, ptr(self.cls_max), code), keep=())
         self.op_topk = K.RawOp("lwdetr_topk", (ptr(self.cls_max), B, S, nq, ptr(self.topk_idx), None, 0), keep=())
         self.op_dec_inputs = K.RawOp("lwdetr_decoder_inputs", (
             ptr(self.enc_delta), ptr(self.props_sel), ptr(self.refpoint), ptr(self.vr), L, ptr(self.query_feat),
@@ -620,7 +661,8 @@ class ForwardPlan:
             op(stream)
         # ---- two-stage selection (group 0 only at inference, transformer.py:229-264)
         if forced_topk is None:
-            self.op_rowmax(stream)
+            if not self.use_chain:
+                self.op_rowmax(stream)
             self.op_topk(stream)
         else:
             self.topk_idx.copy_(forced_topk)
@@ -645,7 +687,7 @@ class ForwardPlan:
             return None
         out = self.output_dict(enc_logits, enc_boxes, cls, coord)
         if collect is not None:
-            if forced_topk is not None:
+            if forced_topk is not None and not self.use_chain:
                 self.op_rowmax(stream)
             collect.update({"topk_idx": self.topk_idx.clone(), "enc.class_max": self.cls_max.clone(), "memory": self.memory.view(B, S, d).clone(),
                             "taps_cat": self.taps_cat.clone(), "x": self.x.clone(), "hs": self.hs.clone(),

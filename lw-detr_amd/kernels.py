@@ -374,6 +374,86 @@ class VitBlockOp:
             _nat.check(rc, "vit_block")
 
 
+# ------------------------------------------------------------------------------------------------- row chains (chain.hip)
+CHAIN_MIN_ROWS = 2048           # below this the separate launches spread over more CUs than M / 128 workgroups would
+
+
+def enc_chain_supported(d, dtype, k5=0, ncls=91, nl=3, rows=None) -> bool:
+    """Shapes / dtypes lwdetr_enc_chain is instantiated for; with ``rows`` the launch-plan choice (LWDETR_CHAIN=0/1 forces)."""
+    ok = dtype in (torch.float16, torch.bfloat16) and ((d == 256 and k5 in (0, 640)) or (d == 384 and k5 == 0)) and ncls <= 96 and 1 <= nl <= 6
+    if not ok or rows is None:
+        return ok
+    force = os.environ.get("LWDETR_CHAIN")
+    if force in ("0", "1"):
+        return force == "1"
+    return rows >= CHAIN_MIN_ROWS
+
+
+def chain_pieces(w, kslots=None):
+    """(N, K) f32 weight, N % 32 == 0, K % 64 == 0 -> flat stream of N/32 * K/64 pieces of 4 KB (in 16-bit), tile-major: piece =
+    32 output channels x 64 k-slots = 4 MFMA fragments of 1 KB in lane order (lane l = 32 h + i holds row i, slots 8 h .. 8 h + 7 of
+    the fragment). ``kslots``: channel held by k-slot p (None = natural order: the operand rows come straight from memory;
+    vb_kslot_channels(K): they are an accumulator tile handed on as a B operand)."""
+    n, k = w.shape
+    assert n % 32 == 0 and k % 64 == 0
+    wk = w if kslots is None else w[:, kslots]
+    return wk.reshape(n // 32, 32, k // 64, 4, 2, 8).permute(0, 2, 3, 4, 1, 5).reshape(-1)
+
+
+def pack_enc_chain(d, dtype, w_enc, b_enc, g_enc, be_enc, w_cls, b_cls, w_val, b_val, cv2=None):
+    """Host-side packing for lwdetr_enc_chain (f32 master tensors in) -> (stream of ``dtype``, vec f32).
+    cv2 = (w2 (d, k5) BatchNorm-folded, b2 (d), ln_w (d), ln_b (d)) or None. Consumption order: cv2 | values | enc_output | class | 2 zero
+    pieces. Operands that come from memory (cv2's input; without cv2 the `memory` rows) are in natural k order, operands handed on
+    from an accumulator (after a LayerNorm) in k-slot order."""
+    f = lambda t: t.detach().float().cpu()
+    w_enc, b_enc, g_enc, be_enc, w_cls, b_cls, w_val, b_val = map(f, (w_enc, b_enc, g_enc, be_enc, w_cls, b_cls, w_val, b_val))
+    perm = vb_kslot_channels(d)
+    mem_slots = perm if cv2 is not None else None
+    ncls = w_cls.shape[0]
+    assert w_enc.shape == (d, d) and w_cls.shape[1] == d and ncls <= 96 and w_val.shape[1] == d and w_val.shape[0] % d == 0
+    nl = w_val.shape[0] // d
+    parts, vec = [], []
+    if cv2 is not None:
+        w2, b2, lw, lb = map(f, cv2)
+        assert w2.shape[0] == d and w2.shape[1] % 64 == 0
+        parts.append(chain_pieces(w2))
+        vec += [b2, lw, lb]
+    parts.append(chain_pieces(w_val, mem_slots))
+    parts.append(chain_pieces(w_enc, mem_slots))
+    wc = torch.zeros(96, d); wc[:ncls] = w_cls
+    bc = torch.zeros(96); bc[:ncls] = b_cls
+    parts.append(chain_pieces(wc, perm))
+    parts.append(torch.zeros(2 * 2048))
+    bv = torch.zeros(6 * d); bv[:nl * d] = b_val
+    vec += [b_enc, g_enc, be_enc, bc, bv]
+    vec = torch.cat(vec)
+    nvec = (vec.numel() * 4 + 4095) // 4096 * 4096 // 4
+    vec = torch.cat([vec, torch.zeros(nvec - vec.numel())]).contiguous()
+    return torch.cat(parts).to(dtype).contiguous(), vec
+
+
+class EncChainOp:
+    """[C2f.cv2 + LayerNorm ->] memory -> value projections, enc_output + LayerNorm, class logits + row max: one launch (lwdetr_enc_chain)."""
+
+    def __init__(self, inp, ld_in, k5, memory, om, cls, ld_cls, cls_max, values, rowvalid, notpad, stream, vec, *, M, d, npix, S, lsi,
+                 total_rows, ncls, eps_p, eps_e):
+        nl = len(values)
+        assert stream.dtype == inp.dtype == om.dtype and vec.dtype == torch.float32 and cls_max.dtype == torch.float32
+        assert stream.numel() * 2 == _nat.lib().lwdetr_enc_chain_pieces(d, k5, nl) * 4096, "stream size"
+        assert vec.numel() == _nat.lib().lwdetr_enc_chain_vec_floats(d, k5), "vec size"
+        self._vals = (C.c_void_p * nl)(*[v.data_ptr() for v in values])
+        self.args = (_ptr(inp), ld_in, k5, _ptr(memory), _ptr(om), _ptr(cls), ld_cls, _ptr(cls_max), self._vals, nl, _ptr(rowvalid),
+                     _ptr(notpad), _ptr(stream), _ptr(vec), M, d, npix, S, lsi, total_rows, ncls, float(eps_p), float(eps_e),
+                     _nat.dtype_code(inp.dtype))
+        self._keep = (inp, memory, om, cls, cls_max, values, rowvalid, notpad, stream, vec)
+        self._fn = _nat.lib().lwdetr_enc_chain
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "enc_chain")
+
+
 class RawOp:
     """Generic pre-bound launch: ``fn(*args, stream)`` of the C ABI (keeps the tensors behind the pointers alive)."""
 

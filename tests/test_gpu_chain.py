@@ -1,0 +1,75 @@
+"""GPU: the row-chain kernel (lwdetr_enc_chain, csrc/chain.hip) against a plain PyTorch fp32 reference of the same chain with the
+unfused launches' rounding points: [cv2 1x1 conv + SiLU + LayerNorm ->] memory -> value projections (padding mask on output rows),
+enc_output on rows with invalid proposals zeroed + LayerNorm, class logits + row maximum."""
+import pytest
+import torch
+
+import lwdetr_amd  # noqa: F401
+from lwdetr_amd import kernels as K
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ln(x, g, b, eps):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), g, b, eps)
+
+
+@pytest.mark.parametrize("d,k5,dtype,B,npix", [(256, 640, torch.float16, 2, 1600), (256, 640, torch.bfloat16, 3, 100), (256, 0, torch.float16, 1, 333),
+                                                (256, 0, torch.bfloat16, 2, 1600), (384, 0, torch.float16, 2, 2125), (384, 0, torch.bfloat16, 1, 77)])
+def test_enc_chain_matches_torch(d, k5, dtype, B, npix):
+    g = torch.Generator().manual_seed(d + k5 + npix)
+    r = lambda *s: torch.randn(*s, generator=g)
+    nl, ncls, S = 3, 91, npix
+    M = B * npix
+    w_enc, b_enc, g_enc, be_enc = r(d, d) / 16, r(d) * 0.5, 1 + 0.1 * r(d), 0.1 * r(d)
+    w_cls, b_cls = r(ncls, d) / 16, r(ncls)
+    w_val, b_val = r(nl * d, d) / 16, r(nl * d) * 0.5
+    cv2 = (r(d, k5) / 25, r(d) * 0.5, 1 + 0.1 * r(d), 0.1 * r(d)) if k5 else None
+    stream, vec = K.pack_enc_chain(d, dtype, w_enc, b_enc, g_enc, be_enc, w_cls, b_cls, w_val, b_val, cv2=cv2)
+    x = (r(M, k5 or d) * (1.0 if k5 else 1.5)).to(dtype)
+    rowvalid = (torch.rand(M, generator=g) > 0.3).to(torch.uint8)
+    notpad = (torch.rand(M, generator=g) > 0.2).to(torch.uint8)
+    # ---- reference: fp32 arithmetic on the 16-bit operands, every stage output rounded to the storage type
+    T = lambda t: t.to(dtype).float()
+    Wt = lambda w: w.to(dtype).float()
+    xf = x.float()
+    if k5:
+        z = T(torch.nn.functional.silu(xf @ Wt(cv2[0]).T + cv2[1]))
+        mem = T(_ln(z, cv2[2], cv2[3], 1e-6))
+    else:
+        mem = xf
+    vals = T(mem @ Wt(w_val).T + b_val) * notpad[:, None].float()
+    om = T(_ln(T((mem * rowvalid[:, None].float()) @ Wt(w_enc).T + b_enc), g_enc, be_enc, 1e-5))
+    cls = T(om @ Wt(w_cls).T + b_cls)
+    # ---- kernel
+    dev = lambda t: t.to(DEV)
+    memory = torch.full((M, d), 7.0, dtype=dtype, device=DEV)
+    omo = torch.full((M, d), 7.0, dtype=dtype, device=DEV)
+    clso = torch.full((M, 96), 7.0, dtype=dtype, device=DEV)
+    cmax = torch.full((M,), 7.0, dtype=torch.float32, device=DEV)
+    values = [torch.full((M, d), 7.0, dtype=dtype, device=DEV) for _ in range(nl)]
+    xin = dev(x)
+    op = K.EncChainOp(xin, k5 or d, k5, memory if k5 else None, omo, clso, 96, cmax, values, dev(rowvalid), dev(notpad), dev(stream), dev(vec),
+                      M=M, d=d, npix=npix, S=S, lsi=0, total_rows=M, ncls=ncls, eps_p=1e-6, eps_e=1e-5)
+    op()
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+
+    def close(got, ref, what, k=3.0):
+        got, ref = got.float().cpu(), ref
+        err = (got - ref).abs()
+        bound = k * ulp * ref.abs().clamp(min=0.25)
+        frac = (err > bound).float().mean().item()
+        assert frac < 2e-3 and err.max().item() < 16 * k * ulp * max(1.0, ref.abs().max().item()), (what, frac, err.max().item())
+
+    if k5:
+        close(memory, mem, "memory")
+    for i in range(nl):
+        close(values[i], vals[:, i * d:(i + 1) * d], f"values[{i}]")
+        assert (values[i].float().cpu()[notpad == 0] == 0).all()
+    close(omo, om, "om", k=4.0)
+    close(clso[:, :ncls], cls, "cls", k=6.0)
+    assert (clso[:, ncls:] == 0).all()
+    # the row maximum is the maximum of the kernel's own (rounded) class logits, exactly
+    assert torch.equal(cmax, clso[:, :ncls].float().max(1).values)
