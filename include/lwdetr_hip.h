@@ -220,6 +220,33 @@ int lwdetr_enc_chain(const void* in, long ld_in, int k5, void* memory, void* om,
                      const void* wstream, const float* vec, long M, int D, int npix, int S, int lsi, long total_rows,
                      int ncls, float eps_p, float eps_e, int dtype, void* hip_stream);
 
+/* lwdetr_row_chain: a run-time program of up to 6 Linear stages over rows that never mix (16-bit dtypes, D in {256, 384}); replaces
+ * the decoder's small GEMM + LayerNorm launches: self_attn.out_proj + residual + norm1 (+ `tgt + query_pos` -> sampling_offsets |
+ * attention_weights Linear), cross_attn.output_proj + residual + norm2 (models/transformer.py:498-506, ms_deform_attn.py:117-123,
+ * :142), bbox_embed / class_embed on all decoder layers (models/lwdetr.py:149-159), enc_out_bbox_embed on the selected rows
+ * (transformer.py:236-240), ref_point_head (transformer.py:28-39, :352-355).
+ *   FULL stage: y = W x + b (+ `res` rows when RES) (ReLU) -> rounded -> (LayerNorm(eps) with affine -> rounded) (-> stored to `out`,
+ *               row stride ldo) -> the operand of the following stages (+ `qpos` rows, rounded, when ADDQ); N = D; stage 0 may
+ *               contract over k_in = 2 D input channels.
+ *   SIDE stage: out[:, 0:n] = W x + b from the current operand (row stride ldo >= ceil4(n); columns up to ceil4(n) are written).
+ * in (M, ld_in): k_in channels per row. wstream / vec: lwdetr_amd.kernels.pack_row_chain - 4 KB pieces (32 output channels x 64
+ * k-slots in MFMA lane order), stage after stage, + 2 zero pieces; f32 vectors stage after stage: bias (D, or 32 * ceil(n / 32) for a
+ * SIDE stage), then gamma (D), beta (D) when LN. */
+enum { LWDETR_CHAIN_FULL = 0, LWDETR_CHAIN_SIDE = 1 };
+enum { LWDETR_CHAIN_RES = 1, LWDETR_CHAIN_RELU = 2, LWDETR_CHAIN_LN = 4, LWDETR_CHAIN_STORE = 8, LWDETR_CHAIN_ADDQ = 16 };
+typedef struct { int kind; int n; int flags; float eps; void* out; long ldo; } lwdetr_chain_stage;
+typedef struct {
+    const void* in; long ld_in; int k_in;
+    const void* res; long ld_res;
+    const void* qpos; long ld_q;
+    const void* wstream; const float* vec;
+    long M; int D; int nst;
+    lwdetr_chain_stage st[6];
+} lwdetr_chain_desc;
+long lwdetr_row_chain_pieces(const lwdetr_chain_desc* desc);
+long lwdetr_row_chain_vec_floats(const lwdetr_chain_desc* desc);
+int lwdetr_row_chain(const lwdetr_chain_desc* desc, int dtype, void* hip_stream);
+
 /* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
  * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */
 int lwdetr_select_gather(const void* om, const void* enc_cls, long ldc, const float* props, const int64_t* idx,

@@ -53,6 +53,20 @@ class AttnDesc(C.Structure):
                 ("sub_len", C.c_int), ("kind", C.c_int), ("vt_slack", C.c_int)]
 
 
+CHAIN_FULL, CHAIN_SIDE = 0, 1
+CHAIN_RES, CHAIN_RELU, CHAIN_LN, CHAIN_STORE, CHAIN_ADDQ = 1, 2, 4, 8, 16
+
+
+class ChainStage(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n", C.c_int), ("flags", C.c_int), ("eps", C.c_float), ("out", C.c_void_p), ("ldo", C.c_long)]
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("ld_in", C.c_long), ("k_in", C.c_int), ("res", C.c_void_p), ("ld_res", C.c_long),
+                ("qpos", C.c_void_p), ("ld_q", C.c_long), ("wstream", C.c_void_p), ("vec", C.c_void_p), ("M", C.c_long),
+                ("D", C.c_int), ("nst", C.c_int), ("st", ChainStage * 6)]
+
+
 def is_built() -> bool:
     return os.path.exists(LIB_PATH)
 
@@ -93,6 +107,11 @@ def lib():
         l.lwdetr_enc_chain_vec_floats.restype = C.c_long
         l.lwdetr_enc_chain_pieces.argtypes = [i, i, i]
         l.lwdetr_enc_chain_pieces.restype = C.c_long
+        l.lwdetr_row_chain.argtypes = [C.POINTER(ChainDesc), i, vp]
+        l.lwdetr_row_chain_pieces.argtypes = [C.POINTER(ChainDesc)]
+        l.lwdetr_row_chain_pieces.restype = C.c_long
+        l.lwdetr_row_chain_vec_floats.argtypes = [C.POINTER(ChainDesc)]
+        l.lwdetr_row_chain_vec_floats.restype = C.c_long
         l.lwdetr_select_gather.argtypes = [vp, vp, lg, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         l.lwdetr_decoder_inputs.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]
         l.lwdetr_box_reparam.argtypes = [vp, vp, lg, vp, lg, i, vp]
@@ -108,7 +127,7 @@ def lib():
         l.lwdetr_prof_kernel_name.restype = C.c_char_p
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
         for fn in ("lwdetr_msda_forward", "lwdetr_msda_backward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
-                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_mlp_fused", "lwdetr_vit_block", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
+                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_enc_chain", "lwdetr_row_chain", "lwdetr_mlp_fused", "lwdetr_vit_block", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
                    "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_postprocess_packed", "lwdetr_finalize_outputs", "lwdetr_resize_normalize", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int
         _lib = l

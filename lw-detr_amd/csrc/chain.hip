@@ -166,10 +166,9 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         // the input rows with a vmcnt that does not know of the DMAs: every DMA issued before that wait would have to land first.
         ring.fill((PF ? PPT5 : PPT) + 2 + 4);
     }
-    // fake uses: hipcc places its own wait for the input rows and flags HERE, before the ring fill of the first begin_tile
-#pragma unroll
-    for (int t = 0; t < KSI; ++t) asm volatile("" :: "v"(xin[t]));
-    asm volatile("" :: "v"((int)rv), "v"((int)npd));
+    // an explicit vmcnt(0) the compiler can see (a real S_WAITCNT, not inline assembly): hipcc's own waits for the input rows and flags
+    // are satisfied HERE, before the ring fill of the first begin_tile, and it adds none behind it
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     auto frag = [&](int g) -> V8 {           // global fragment index g = 4 * piece + fragment
         return *(const V8*)(smem + (((unsigned)g & (NSLOT * 4 - 1)) << 10) + lane16);
     };
@@ -341,6 +340,254 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ generic row chain
+// A run-time program of up to 6 stages over a wave's 32 rows (decoder: output projections + LayerNorm (+ the sampling-offset /
+// attention-weight Linear), the box / class heads, the two-stage box head, ref_point_head):
+//   FULL stage: y = W x + b (+ residual rows loaded in the prologue) (ReLU) -> rounded -> (LayerNorm with affine -> rounded)
+//               (-> stored to `out` rows) -> becomes the operand of the following stages (optionally + qpos, rounded: the
+//               reference's `tgt + query_pos`); N = D. The first FULL stage of a chain may contract over K0 = 2 D input channels.
+//   SIDE stage: out[:, 0:ncols] = W x + b from the CURRENT operand, tile by tile; the operand stays.
+enum { CS_FULL = 0, CS_SIDE = 1 };
+enum { CF_RES = 1, CF_RELU = 2, CF_LN = 4, CF_STORE = 8, CF_ADDQ = 16 };
+struct ChainStageK { int kind, nt, flags, ncols, bias_off, gam_off, bet_off; float eps; void* out; long ldo; unsigned out_bytes; };
+struct MlpChainParams {
+    const void* in; long ld_in; unsigned in_bytes;
+    const void* res; long ld_res; unsigned res_bytes;
+    const void* qpos; long ld_q; unsigned q_bytes;
+    const void* wstream; const float* vec; int vec_dpw; int np; long M; int nst;
+    ChainStageK st[6];
+};
+constexpr int CH_VEC_MAX_B = 16384;
+
+template <typename T, int D, int KS0, bool RES, bool QP>
+__global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const MlpChainParams p) {
+    typedef typename Vec<T>::v8 V8;
+    constexpr int KS = D / 16, NTI = D / 32, PPT = D / 64, PPT0 = KS0 / 4;
+    constexpr int NSLOT = 32;
+    static_assert(KS % CH_RD == 0 && KS0 % CH_RD == 0, "the fragment read-ahead ring must divide every tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float* vec = (const float*)(smem + NSLOT * CH_PIECE_B);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    const long t0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long mrow = t0 + j;
+    const bool live = mrow < p.M;
+
+    // ---- prologue loads (older than every weight DMA): input rows as B operands (natural k order), residual / qpos rows in
+    // accumulator layout (16-byte pieces: channels 32 n + 16 jb + 8 h .. + 7 of row j)
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const unsigned in_off = live ? (unsigned)(mrow * p.ld_in * 2) : 0x80000000u;
+    V8 xin[KS0];
+#pragma unroll
+    for (int t = 0; t < KS0; ++t)
+        xin[t] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(r_in, in_off + (unsigned)((16 * t + 8 * h) * 2), 0, 0));
+    cu32x4 xr[RES ? NTI : 1][2], xq[QP ? NTI : 1][2];
+    if constexpr (RES) {
+        const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)p.res_bytes, 0x00020000);
+        const unsigned off = live ? (unsigned)(mrow * p.ld_res * 2) : 0x80000000u;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) xr[n][jb] = __builtin_amdgcn_raw_buffer_load_b128(r_res, off + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+    }
+    if constexpr (QP) {
+        const __amdgpu_buffer_rsrc_t r_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.qpos, 0, (int)p.q_bytes, 0x00020000);
+        const unsigned off = live ? (unsigned)(mrow * p.ld_q * 2) : 0x80000000u;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) xq[n][jb] = __builtin_amdgcn_raw_buffer_load_b128(r_q, off + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+    }
+    WRing<NSLOT> ring;
+    ring.src = (const char*)p.wstream; ring.lds0 = lds0; ring.np = p.np; ring.issued = 0; ring.wave = wave; ring.lane16 = lane16;
+    {
+        const char* vsrc = (const char*)p.vec;
+        for (int i = 0; i < p.vec_dpw; ++i) {
+            const unsigned kb = (unsigned)(wave * p.vec_dpw + i) * 1024u;
+            ring.dma1k(vsrc, kb + lane16, lds0 + NSLOT * CH_PIECE_B + kb);
+        }
+        ring.fill(PPT0 + 2 + 4);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), visible to the compiler: see enc_chain_kernel
+    auto frag = [&](int g) -> V8 { return *(const V8*)(smem + (((unsigned)g & (NSLOT * 4 - 1)) << 10) + lane16); };
+    auto bias16 = [&](const float* src) -> f32x16 {
+        f32x16 r;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 v = *(const f32x4*)(src + 8 * b + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[4 * b + e] = v[e];
+        }
+        return r;
+    };
+    int pc = 0;
+    bool first = true;
+    V8 fr[CH_RD];
+    auto tile = [&](auto& x, auto nf_tag, f32x16 acc) -> f32x16 {
+        constexpr int nf = decltype(nf_tag)::value;
+        const int g0 = 4 * pc;
+#pragma unroll
+        for (int f = 0; f < nf; ++f) {
+            const V8 a = fr[f % CH_RD];
+            fr[f % CH_RD] = frag(g0 + f + CH_RD);
+            acc = Mma32c<T>::k16(a, x[f], acc);
+        }
+        pc += nf / 4;
+        return acc;
+    };
+    auto next_tile = [&](int n) {
+        if (first) first = false;
+        else ring.template begin_tile<NSLOT - 2 * PPT - 2>(pc, n);
+    };
+    V8 xf[KS];
+    if constexpr (KS0 == KS) {
+#pragma unroll
+        for (int t = 0; t < KS; ++t) xf[t] = xin[t];
+    }
+    ring.template begin_tile<4>(0, PPT0);
+#pragma unroll
+    for (int i = 0; i < CH_RD; ++i) fr[i] = frag(i);
+
+    // FULL stage over operand x (nf fragments per tile)
+    auto full = [&](const ChainStageK& st, auto& x, auto nf_tag) {
+        constexpr int nf = decltype(nf_tag)::value;
+        const float* bsrc = vec + st.bias_off;
+        unsigned xp[NTI][8];
+        float s = 0.f;
+        const bool relu = st.flags & CF_RELU, has_res = RES && (st.flags & CF_RES);
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+            next_tile(nf / 4);
+            f32x16 init = bias16(bsrc + 32 * n);
+            if constexpr (RES) {
+                if (has_res) {
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const cu32x4 own = crows8(xr[n][jb][0], xr[n][jb][1], xr[n][jb][2], xr[n][jb][3]);     // its own inverse
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned ow_ = own[q];
+                            float v0, v1; cunpack2<T>(ow_, v0, v1);
+                            init[8 * jb + 2 * q] += v0; init[8 * jb + 2 * q + 1] += v1;
+                        }
+                    }
+                }
+            }
+            const f32x16 acc = tile(x, nf_tag, init);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                float a0 = acc[2 * d], a1 = acc[2 * d + 1];
+                if (relu) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); }
+                const unsigned w = cpack2<T>(a0, a1);
+                xp[n][d] = w;
+                float v0, v1; cunpack2<T>(w, v0, v1);
+                s += v0 + v1;
+            }
+        }
+        float mean = 0.f, rstd = 1.f;
+        const bool ln = st.flags & CF_LN;
+        if (ln) {
+            s += __shfl_xor(s, 32);
+            mean = s * (1.f / D);
+            float v = 0.f;
+#pragma unroll
+            for (int n = 0; n < NTI; ++n)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    float v0, v1; cunpack2<T>(xp[n][d], v0, v1);
+                    v0 -= mean; v1 -= mean;
+                    v = fmaf(v0, v0, v); v = fmaf(v1, v1, v);
+                }
+            v += __shfl_xor(v, 32);
+            rstd = 1.f / sqrtf(v * (1.f / D) + st.eps);
+        }
+        const float* gam = vec + st.gam_off; const float* bet = vec + st.bet_off;
+        const bool store = st.flags & CF_STORE, addq = QP && (st.flags & CF_ADDQ);
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(store ? st.out : (void*)p.in, 0, store ? (int)st.out_bytes : 0, 0x00020000);
+        const unsigned ooff = live ? (unsigned)(mrow * st.ldo * 2) : 0x80000000u;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+            unsigned w[8];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c0 = 32 * n + 8 * b + 4 * h;
+                if (ln) {
+                    const f32x4 g = *(const f32x4*)(gam + c0), be = *(const f32x4*)(bet + c0);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        float v0, v1; cunpack2<T>(xp[n][2 * b + d], v0, v1);
+                        w[2 * b + d] = cpack2<T>(fmaf((v0 - mean) * rstd, g[2 * d], be[2 * d]), fmaf((v1 - mean) * rstd, g[2 * d + 1], be[2 * d + 1]));
+                    }
+                } else {
+                    w[2 * b] = xp[n][2 * b]; w[2 * b + 1] = xp[n][2 * b + 1];
+                }
+            }
+            if (store) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const cu32x4 ow = crows8(w[4 * jb], w[4 * jb + 1], w[4 * jb + 2], w[4 * jb + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(ow, r_out, ooff + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+                }
+            }
+            if constexpr (QP) {
+                if (addq) {              // operand of the following stages = T(x + qpos): the reference's `tgt + query_pos`
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const cu32x4 own = crows8(xq[n][jb][0], xq[n][jb][1], xq[n][jb][2], xq[n][jb][3]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned qw = own[q];
+                            float q0, q1, v0, v1; cunpack2<T>(qw, q0, q1); cunpack2<T>(w[4 * jb + q], v0, v1);
+                            w[4 * jb + q] = cpack2<T>(v0 + q0, v1 + q1);
+                        }
+                    }
+                }
+            }
+            xf[2 * n] = __builtin_bit_cast(V8, cu32x4{w[0], w[1], w[2], w[3]});
+            xf[2 * n + 1] = __builtin_bit_cast(V8, cu32x4{w[4], w[5], w[6], w[7]});
+        }
+    };
+    // SIDE stage from the current operand
+    auto side = [&](const ChainStageK& st) {
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(st.out, 0, (int)st.out_bytes, 0x00020000);
+        const unsigned ooff = live ? (unsigned)(mrow * st.ldo * 2) : 0x80000000u;
+        const bool wide = (st.ldo % 8 == 0) && (st.ncols % 8 == 0);
+        const float* bsrc = vec + st.bias_off;
+#pragma unroll 1
+        for (int vt = 0; vt < st.nt; ++vt) {
+            next_tile(PPT);
+            const f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bsrc + 32 * vt));
+            unsigned w[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) w[d] = cpack2<T>(acc[2 * d], acc[2 * d + 1]);
+            if (wide) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const cu32x4 ow = crows8(w[4 * jb], w[4 * jb + 1], w[4 * jb + 2], w[4 * jb + 3]);
+                    const int c0 = 32 * vt + 16 * jb + 8 * h;
+                    __builtin_amdgcn_raw_buffer_store_b128(ow, r_out, c0 < st.ncols ? ooff + (unsigned)(c0 * 2) : 0x80000000u, 0, 0);
+                }
+            } else {                // 8-byte pieces: channels 32 vt + 8 b + 4 h .. + 3 (ldo % 4 == 0; pad columns up to ceil4(ncols) are written)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c0 = 32 * vt + 8 * b + 4 * h;
+                    typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(cu32x2{w[2 * b], w[2 * b + 1]}, r_out, c0 < st.ncols ? ooff + (unsigned)(c0 * 2) : 0x80000000u, 0, 0);
+                }
+            }
+        }
+    };
+#pragma unroll 1
+    for (int si = 0; si < p.nst; ++si) {
+        const ChainStageK& st = p.st[si];
+        if (st.kind == CS_SIDE) side(st);
+        else if (KS0 != KS && si == 0) full(st, xin, std::integral_constant<int, KS0>{});
+        else full(st, xf, std::integral_constant<int, KS>{});
+    }
+}
+
 template <typename T, int D, bool PF, int K5>
 int launch_enc(const EncParams& p, hipStream_t st) {
     constexpr int NSLOT = 32, NCT = 3;
@@ -371,7 +618,124 @@ int dispatch_enc(const EncParams& p, int D, int k5, hipStream_t st) {
     return LWDETR_ERR_UNSUPPORTED;
 }
 
+template <typename T, int D, int KS0, bool RES, bool QP>
+int launch_mlp_chain(const MlpChainParams& p, hipStream_t st, double flops, double bytes) {
+    constexpr size_t lds = (size_t)32 * CH_PIECE_B + CH_VEC_MAX_B;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)mlp_chain_kernel<T, D, KS0, RES, QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done[dev] = true;
+    }
+    ProfScope ps(KID_CHAIN, flops, bytes, st);
+    hipLaunchKernelGGL((mlp_chain_kernel<T, D, KS0, RES, QP>), dim3((unsigned)((p.M + 127) / 128)), dim3(256), lds, st, p);
+    return lwdetr_check_launch();
+}
+
+template <typename T, int D>
+int dispatch_mlp_chain(const MlpChainParams& p, int k_in, bool res, bool qp, hipStream_t st, double flops, double bytes) {
+    // D = 384 is instantiated without residual / qpos rows only: with them the rolled stage loop needs more than the 512 registers
+    // of a lone wave (hipcc 7.2 spills 280 - 950 bytes per lane); the decoder chains of the d = 384 models stay on separate launches
+    if constexpr (D == 256) {
+        if (k_in == 2 * D) return (res || qp) ? LWDETR_ERR_UNSUPPORTED : launch_mlp_chain<T, D, D / 8, false, false>(p, st, flops, bytes);
+        if (k_in != D) return LWDETR_ERR_UNSUPPORTED;
+        if (qp) return res ? launch_mlp_chain<T, D, D / 16, true, true>(p, st, flops, bytes) : LWDETR_ERR_UNSUPPORTED;
+        return res ? launch_mlp_chain<T, D, D / 16, true, false>(p, st, flops, bytes) : launch_mlp_chain<T, D, D / 16, false, false>(p, st, flops, bytes);
+    } else {
+        if (k_in != D || res || qp) return LWDETR_ERR_UNSUPPORTED;
+        return launch_mlp_chain<T, D, D / 16, false, false>(p, st, flops, bytes);
+    }
+}
+
+// vec layout / piece count of a chain description (shared by the size helpers and the launch)
+struct ChainLayout { long pieces, vec_floats; int bias_off[6], gam_off[6], bet_off[6], nt[6]; bool ok; };
+ChainLayout chain_layout(const lwdetr_chain_desc* d) {
+    ChainLayout L = {};
+    if (!d || (d->D != 256 && d->D != 384) || d->nst < 1 || d->nst > 6 || (d->k_in != d->D && d->k_in != 2 * d->D)) return L;
+    long off = 0, pieces = 0;
+    for (int i = 0; i < d->nst; ++i) {
+        const lwdetr_chain_stage& s = d->st[i];
+        L.bias_off[i] = (int)off;
+        if (s.kind == LWDETR_CHAIN_FULL) {
+            const int k = (i == 0) ? d->k_in : d->D;
+            if (i > 0 && d->k_in != d->D && false) return L;
+            L.nt[i] = d->D / 32;
+            off += d->D;
+            if (s.flags & LWDETR_CHAIN_LN) { L.gam_off[i] = (int)off; off += d->D; L.bet_off[i] = (int)off; off += d->D; }
+            pieces += (long)(d->D / 32) * (k / 64);
+        } else if (s.kind == LWDETR_CHAIN_SIDE) {
+            if (s.n < 1 || (i == 0 && d->k_in != d->D)) return L;
+            L.nt[i] = (s.n + 31) / 32;
+            off += 32L * L.nt[i];
+            pieces += (long)L.nt[i] * (d->D / 64);
+        } else return L;
+    }
+    L.pieces = pieces + 2;
+    L.vec_floats = (off * 4 + 4095) / 4096 * 4096 / 4;
+    L.ok = L.vec_floats * 4 <= CH_VEC_MAX_B;
+    return L;
+}
+
 }  // namespace
+
+extern "C" long lwdetr_row_chain_pieces(const lwdetr_chain_desc* d) { const ChainLayout L = chain_layout(d); return L.ok ? L.pieces : -1; }
+extern "C" long lwdetr_row_chain_vec_floats(const lwdetr_chain_desc* d) { const ChainLayout L = chain_layout(d); return L.ok ? L.vec_floats : -1; }
+
+extern "C" int lwdetr_row_chain(const lwdetr_chain_desc* d, int dtype, void* hip_stream) {
+    const ChainLayout L = chain_layout(d);
+    if (!L.ok) return LWDETR_ERR_UNSUPPORTED;
+    if (!d->in || !d->wstream || !d->vec || d->M < 0 || d->ld_in % 8 != 0 || ((uintptr_t)d->in | (uintptr_t)d->wstream | (uintptr_t)d->vec) % 16 != 0) return LWDETR_ERR_BAD_ARG;
+    if (d->M == 0) return LWDETR_OK;
+    if (d->k_in != d->D && d->st[0].kind != LWDETR_CHAIN_FULL) return LWDETR_ERR_BAD_ARG;
+    if ((d->res && (d->ld_res % 8 != 0 || (uintptr_t)d->res % 16 != 0)) || (d->qpos && (d->ld_q % 8 != 0 || (uintptr_t)d->qpos % 16 != 0))) return LWDETR_ERR_BAD_ARG;
+    MlpChainParams p = {};
+    const auto bytes_of = [&](long ld) -> double { return (double)d->M * ld * 2.0; };
+    if (bytes_of(d->ld_in) >= 2147483000.0 || (d->res && bytes_of(d->ld_res) >= 2147483000.0) || (d->qpos && bytes_of(d->ld_q) >= 2147483000.0)) return LWDETR_ERR_UNSUPPORTED;
+    p.in = d->in; p.ld_in = d->ld_in; p.in_bytes = (unsigned)bytes_of(d->ld_in);
+    p.res = d->res; p.ld_res = d->ld_res; p.res_bytes = d->res ? (unsigned)bytes_of(d->ld_res) : 0;
+    p.qpos = d->qpos; p.ld_q = d->ld_q; p.q_bytes = d->qpos ? (unsigned)bytes_of(d->ld_q) : 0;
+    p.wstream = d->wstream; p.vec = d->vec; p.vec_dpw = (int)(L.vec_floats * 4 / 4096); p.np = (int)L.pieces; p.M = d->M; p.nst = d->nst;
+    double flops = 0.0, bytes = bytes_of(d->ld_in < d->k_in ? d->ld_in : d->k_in);
+    bool uses_res = false, uses_q = false;
+    for (int i = 0; i < d->nst; ++i) {
+        const lwdetr_chain_stage& s = d->st[i];
+        ChainStageK& k = p.st[i];
+        k.kind = s.kind == LWDETR_CHAIN_FULL ? CS_FULL : CS_SIDE; k.nt = L.nt[i]; k.flags = s.flags; k.eps = s.eps;
+        k.bias_off = L.bias_off[i]; k.gam_off = L.gam_off[i]; k.bet_off = L.bet_off[i];
+        const bool stores = s.kind == LWDETR_CHAIN_SIDE || (s.flags & LWDETR_CHAIN_STORE);
+        if (stores) {
+            if (!s.out || s.ldo % 4 != 0 || (uintptr_t)s.out % 16 != 0 || bytes_of(s.ldo) >= 2147483000.0) return LWDETR_ERR_BAD_ARG;
+            if (s.kind == LWDETR_CHAIN_FULL && (s.ldo % 8 != 0 || s.ldo < d->D)) return LWDETR_ERR_BAD_ARG;
+            if (s.kind == LWDETR_CHAIN_SIDE && s.ldo < (s.n + 3) / 4 * 4) return LWDETR_ERR_BAD_ARG;
+            k.out = s.out; k.ldo = s.ldo; k.out_bytes = (unsigned)bytes_of(s.ldo);
+            bytes += (double)d->M * (s.kind == LWDETR_CHAIN_FULL ? d->D : s.n) * 2.0;
+        }
+        k.ncols = s.kind == LWDETR_CHAIN_SIDE ? s.n : d->D;
+        if (s.kind == LWDETR_CHAIN_FULL) {
+            if (s.flags & LWDETR_CHAIN_RES) uses_res = true;
+            if (s.flags & LWDETR_CHAIN_ADDQ) uses_q = true;
+            flops += 2.0 * d->M * d->D * (i == 0 ? d->k_in : d->D);
+        } else {
+            if (s.flags & ~0) { if (s.flags != 0) return LWDETR_ERR_BAD_ARG; }
+            flops += 2.0 * d->M * d->D * 32.0 * L.nt[i];
+        }
+    }
+    if ((uses_res && !d->res) || (uses_q && !d->qpos) || (uses_q && !uses_res && !d->res)) return LWDETR_ERR_BAD_ARG;
+    if (uses_res) bytes += (double)d->M * d->D * 2.0;
+    if (uses_q) bytes += (double)d->M * d->D * 2.0;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const bool res = d->res != nullptr, qp = d->qpos != nullptr;
+    if (d->D == 256) {
+        if (dtype == DT_F16) return dispatch_mlp_chain<f16, 256>(p, d->k_in, res, qp, st, flops, bytes);
+        if (dtype == DT_BF16) return dispatch_mlp_chain<bf16, 256>(p, d->k_in, res, qp, st, flops, bytes);
+    } else {
+        if (dtype == DT_F16) return dispatch_mlp_chain<f16, 384>(p, d->k_in, res, qp, st, flops, bytes);
+        if (dtype == DT_BF16) return dispatch_mlp_chain<bf16, 384>(p, d->k_in, res, qp, st, flops, bytes);
+    }
+    return LWDETR_ERR_UNSUPPORTED;
+}
 
 extern "C" long lwdetr_enc_chain_vec_floats(int D, int k5) {
     const long f = (k5 ? 3L * D : 0) + 3L * D + 96 + 6L * D;

@@ -437,9 +437,31 @@ class ForwardPlan:
         self.enc_delta = z(B * nq, 4)
         ops = self.ops_sel
         be = f"{t}.enc_out_bbox_embed.0.layers"
-        ops.append(GemmOp(self.om_sel, pw.w(be + ".0.weight"), B * nq, d, d, [seg(s1, 0, d, ldo=d, bias=pw.f(be + ".0.bias"), act=ACT_RELU)]))
-        ops.append(GemmOp(s1, pw.w(be + ".1.weight"), B * nq, d, d, [seg(s2, 0, d, ldo=d, bias=pw.f(be + ".1.bias"), act=ACT_RELU)]))
-        ops.append(GemmOp(s2, pw.w(be + ".2.weight"), B * nq, 4, d, [seg(self.enc_delta, 0, 4, ldo=4, bias=pw.f(be + ".2.bias"))]))
+        sdw = pw.sd
+        chain_plain = K.row_chain_supported(d, self.T)                                  # round 4: rows that never mix -> one launch
+        chain_res = K.row_chain_supported(d, self.T, res=True)
+        chain_q = K.row_chain_supported(d, self.T, res=True, qpos=True) and os.environ.get("LWDETR_DEC_QPOS", "1") != "0"
+        chain_k2 = K.row_chain_supported(d, self.T, k_in=2 * d)
+
+        def row_chain(name, inp, ld_in, k_in, M, stages, **kw):
+            """stages: RowChainOp stage dicts with weights / biases given as state-dict keys (or f32 tensors)."""
+            g = lambda v: sdw[v] if isinstance(v, str) else v
+            for st in stages:
+                st["w"], st["b"] = g(st["w"]), g(st["b"])
+                if st.get("ln") is not None:
+                    st["ln"] = (g(st["ln"][0]), g(st["ln"][1]), st["ln"][2])
+            stream_w, vec = pw.custom_multi(f"row_chain.{name}", lambda: K.RowChainOp.pack(d, self.T, k_in, stages))
+            return K.RowChainOp(inp, ld_in, k_in, stages, stream_w, vec, M=M, d=d, **kw)
+
+        if chain_plain:
+            ops.append(row_chain("enc_bbox", self.om_sel, d, d, B * nq, [
+                dict(kind="full", w=be + ".0.weight", b=be + ".0.bias", relu=True),
+                dict(kind="full", w=be + ".1.weight", b=be + ".1.bias", relu=True),
+                dict(kind="side", w=be + ".2.weight", b=be + ".2.bias", out=self.enc_delta, ldo=4)]))
+        else:
+            ops.append(GemmOp(self.om_sel, pw.w(be + ".0.weight"), B * nq, d, d, [seg(s1, 0, d, ldo=d, bias=pw.f(be + ".0.bias"), act=ACT_RELU)]))
+            ops.append(GemmOp(s1, pw.w(be + ".1.weight"), B * nq, d, d, [seg(s2, 0, d, ldo=d, bias=pw.f(be + ".1.bias"), act=ACT_RELU)]))
+            ops.append(GemmOp(s2, pw.w(be + ".2.weight"), B * nq, 4, d, [seg(self.enc_delta, 0, 4, ldo=4, bias=pw.f(be + ".2.bias"))]))
         # ---- decoder
         ops = self.ops_dec
         M, D = cfg.ca_nheads, d // cfg.ca_nheads
@@ -454,8 +476,13 @@ class ForwardPlan:
         self.hs = z(nl, rq, d)
         r1 = z(rq, d)
         rp = f"{t}.decoder.ref_point_head.layers"
-        ops.append(GemmOp(self.sine, pw.w(rp + ".0.weight"), rq, d, 2 * d, [seg(r1, 0, d, ldo=d, bias=pw.f(rp + ".0.bias"), act=ACT_RELU)]))
-        ops.append(GemmOp(r1, pw.w(rp + ".1.weight"), rq, d, d, [seg(self.qpos, 0, d, ldo=d, bias=pw.f(rp + ".1.bias"))]))
+        if chain_k2:
+            ops.append(row_chain("ref_point_head", self.sine, 2 * d, 2 * d, rq, [
+                dict(kind="full", w=rp + ".0.weight", b=rp + ".0.bias", relu=True),
+                dict(kind="full", w=rp + ".1.weight", b=rp + ".1.bias", out=self.qpos, ldo=d)]))
+        else:
+            ops.append(GemmOp(self.sine, pw.w(rp + ".0.weight"), rq, d, 2 * d, [seg(r1, 0, d, ldo=d, bias=pw.f(rp + ".0.bias"), act=ACT_RELU)]))
+            ops.append(GemmOp(r1, pw.w(rp + ".1.weight"), rq, d, d, [seg(self.qpos, 0, d, ldo=d, bias=pw.f(rp + ".1.bias"))]))
         qd, kd, vtd = z(B, sa_h, nq, sa_hd), z(B, sa_h, nq, sa_hd), z(B, sa_h, sa_hd, nq)
         attd, y, ca = z(rq, d), z(rq, d), z(rq, d)
         # decoder FFN: two launches with the hidden activation on chip (lwdetr_ffn_partial / _finish) unless
@@ -476,17 +503,23 @@ class ForwardPlan:
         qpos_pre = os.environ.get("LWDETR_DEC_QPOS", "1") != "0" and ld_oa % 8 == 0 and (2 * d) % 128 == 0
         if qpos_pre:
             s_att = K.attention_scale(sa_hd)
-            w_pre = pw.custom(f"{t}.decoder.qpos_pre.w", lambda: torch.cat(
-                [pw.sd[f"{t}.decoder.layers.{i}.self_attn.in_proj_weight"].detach().float()[:2 * d] for i in range(nl)] +
-                [F.pad(torch.cat([pw.sd[f"{t}.decoder.layers.{i}.cross_attn.sampling_offsets.weight"].detach().float(),
-                                  pw.sd[f"{t}.decoder.layers.{i}.cross_attn.attention_weights.weight"].detach().float()], 0),
-                       (0, 0, 0, ld_oa - lp3)) for i in range(nl)], 0))
             g_pre = pw.custom(f"{t}.decoder.qpos_pre.gamma", lambda: torch.cat(
                 [torch.full((d,), s_att), torch.ones(d)] * nl), dtype=torch.float32)
-            pqk, poa = z(rq, nl * 2 * d), z(rq, nl * ld_oa)
-            ops.append(GemmOp(self.qpos, w_pre, rq, nl * (2 * d + ld_oa), d, [
-                seg(pqk, 0, nl * 2 * d, ldo=nl * 2 * d, gamma=g_pre),
-                seg(poa, nl * 2 * d, nl * (2 * d + ld_oa), ldo=nl * ld_oa)]))
+            if chain_q:      # the layer-front chain forms tgt + query_pos itself (CF_ADDQ): only the q / k products are precomputed
+                w_pre = pw.custom(f"{t}.decoder.qpos_pre.w.qk", lambda: torch.cat(
+                    [pw.sd[f"{t}.decoder.layers.{i}.self_attn.in_proj_weight"].detach().float()[:2 * d] for i in range(nl)], 0))
+                pqk, poa = z(rq, nl * 2 * d), None
+                ops.append(GemmOp(self.qpos, w_pre, rq, nl * 2 * d, d, [seg(pqk, 0, nl * 2 * d, ldo=nl * 2 * d, gamma=g_pre)]))
+            else:
+                w_pre = pw.custom(f"{t}.decoder.qpos_pre.w", lambda: torch.cat(
+                    [pw.sd[f"{t}.decoder.layers.{i}.self_attn.in_proj_weight"].detach().float()[:2 * d] for i in range(nl)] +
+                    [F.pad(torch.cat([pw.sd[f"{t}.decoder.layers.{i}.cross_attn.sampling_offsets.weight"].detach().float(),
+                                      pw.sd[f"{t}.decoder.layers.{i}.cross_attn.attention_weights.weight"].detach().float()], 0),
+                           (0, 0, 0, ld_oa - lp3)) for i in range(nl)], 0))
+                pqk, poa = z(rq, nl * 2 * d), z(rq, nl * ld_oa)
+                ops.append(GemmOp(self.qpos, w_pre, rq, nl * (2 * d + ld_oa), d, [
+                    seg(pqk, 0, nl * 2 * d, ldo=nl * 2 * d, gamma=g_pre),
+                    seg(poa, nl * 2 * d, nl * (2 * d + ld_oa), ldo=nl * ld_oa)]))
         for li in range(nl):
             lay = f"{t}.decoder.layers.{li}"
             ipw, ipb = lay + ".self_attn.in_proj_weight", lay + ".self_attn.in_proj_bias"
@@ -508,26 +541,47 @@ class ForwardPlan:
                     seg(vtd, 0, d, mode=OUT_HEADS_T, bias=pw.f(ipb, lambda b_: b_[2 * d:], "v"), p0=nq, p1=sa_hd, p2=sa_h)]))
             ops.append(AttnOp(qd, kd, vtd, attd, B=B, heads=sa_h, hd=sa_hd, Tp=nq, ldo=d, seqs_per_img=1,
                               seq_tok_stride=nq, keys_per_seq=nq, sub_stride=nq, sub_len=nq, kind=2))
-            ops.append(GemmOp(attd, pw.w(lay + ".self_attn.out_proj.weight"), rq, d, d, [
-                seg(y, 0, d, ldo=d, bias=pw.f(lay + ".self_attn.out_proj.bias"), res=self.xdec, ldres=d)]))
-            ops.append(LayerNormOp(y, pw.f(lay + ".norm1.weight"), pw.f(lay + ".norm1.bias"), self.xdec, rq, d, 1e-5))
             ca_p = lay + ".cross_attn"
+            front_chain = chain_q and qpos_pre
+            if front_chain:
+                # self_attn.out_proj + residual + norm1 -> tgt (stored), tgt + query_pos -> sampling_offsets | attention_weights: one launch
+                ops.append(row_chain(f"dec{li}.front", attd, d, d, rq, [
+                    dict(kind="full", w=lay + ".self_attn.out_proj.weight", b=lay + ".self_attn.out_proj.bias", res=True,
+                         ln=(lay + ".norm1.weight", lay + ".norm1.bias", 1e-5), out=self.xdec, ldo=d, addq=True),
+                    dict(kind="side", w=torch.cat([sdw[ca_p + ".sampling_offsets.weight"].detach().float(), sdw[ca_p + ".attention_weights.weight"].detach().float()], 0),
+                         b=torch.cat([sdw[ca_p + ".sampling_offsets.bias"].detach().float(), sdw[ca_p + ".attention_weights.bias"].detach().float()], 0),
+                         out=oa, ldo=ld_oa)], res=self.xdec, ld_res=d, qpos=self.qpos, ld_q=d))
+            elif chain_res:
+                ops.append(row_chain(f"dec{li}.front_noq", attd, d, d, rq, [
+                    dict(kind="full", w=lay + ".self_attn.out_proj.weight", b=lay + ".self_attn.out_proj.bias", res=True,
+                         ln=(lay + ".norm1.weight", lay + ".norm1.bias", 1e-5), out=self.xdec, ldo=d)], res=self.xdec, ld_res=d))
+            else:
+                ops.append(GemmOp(attd, pw.w(lay + ".self_attn.out_proj.weight"), rq, d, d, [
+                    seg(y, 0, d, ldo=d, bias=pw.f(lay + ".self_attn.out_proj.bias"), res=self.xdec, ldres=d)]))
+                ops.append(LayerNormOp(y, pw.f(lay + ".norm1.weight"), pw.f(lay + ".norm1.bias"), self.xdec, rq, d, 1e-5))
             w_oa = pw.custom(ca_p + ".oa.w", lambda ca_p=ca_p: torch.cat(
                 [pw.sd[ca_p + ".sampling_offsets.weight"].detach().float(),
                  pw.sd[ca_p + ".attention_weights.weight"].detach().float()], 0))
             b_oa = pw.custom(ca_p + ".oa.b", lambda ca_p=ca_p: torch.cat(
                 [pw.sd[ca_p + ".sampling_offsets.bias"].detach().float(),
                  pw.sd[ca_p + ".attention_weights.bias"].detach().float()], 0), dtype=torch.float32)
-            if qpos_pre:
+            if front_chain:
+                pass
+            elif qpos_pre:
                 ops.append(GemmOp(self.xdec, w_oa, rq, lp3, d, [seg(oa, 0, lp3, ldo=ld_oa, bias=b_oa, res=poa[:, li * ld_oa:],
                                                                      ldres=nl * ld_oa)], keep=(poa,)))
             else:
                 ops.append(GemmOp(self.xdec, w_oa, rq, lp3, d, [seg(oa, 0, lp3, ldo=ld_oa, bias=b_oa)], A2=self.qpos))
             ops.append(MsdaFusedOp(self.values[li], self.shapes_t, self.lsi_t, oa, ld_oa, M * L * P * 2, self.ref,
                                    self.vr, ca, B=B, S=S, M=M, D=D, L=L, Q=nq, P=P))
-            ops.append(GemmOp(ca, pw.w(ca_p + ".output_proj.weight"), rq, d, d, [
-                seg(y, 0, d, ldo=d, bias=pw.f(ca_p + ".output_proj.bias"), res=self.xdec, ldres=d)]))
-            ops.append(LayerNormOp(y, pw.f(lay + ".norm2.weight"), pw.f(lay + ".norm2.bias"), self.xdec, rq, d, 1e-5))
+            if chain_res:
+                ops.append(row_chain(f"dec{li}.back", ca, d, d, rq, [
+                    dict(kind="full", w=ca_p + ".output_proj.weight", b=ca_p + ".output_proj.bias", res=True,
+                         ln=(lay + ".norm2.weight", lay + ".norm2.bias", 1e-5), out=self.xdec, ldo=d)], res=self.xdec, ld_res=d))
+            else:
+                ops.append(GemmOp(ca, pw.w(ca_p + ".output_proj.weight"), rq, d, d, [
+                    seg(y, 0, d, ldo=d, bias=pw.f(ca_p + ".output_proj.bias"), res=self.xdec, ldres=d)]))
+                ops.append(LayerNormOp(y, pw.f(lay + ".norm2.weight"), pw.f(lay + ".norm2.bias"), self.xdec, rq, d, 1e-5))
             n3 = (pw.f(lay + ".norm3.weight"), pw.f(lay + ".norm3.bias"), 1e-5, self.xdec,
                   pw.f(f"{t}.decoder.norm.weight"), pw.f(f"{t}.decoder.norm.bias"), 1e-5, self.hs[li], rq, d)
             if ffn_fused:
@@ -551,11 +605,19 @@ class ForwardPlan:
         self.delta = z(rh, 4)
         self.logits = z(rh, self.ldc)
         bb = "bbox_embed.layers"
-        ops.append(GemmOp(hs2, pw.w(bb + ".0.weight"), rh, d, d, [seg(h1, 0, d, ldo=d, bias=pw.f(bb + ".0.bias"), act=ACT_RELU)]))
-        ops.append(GemmOp(h1, pw.w(bb + ".1.weight"), rh, d, d, [seg(h2, 0, d, ldo=d, bias=pw.f(bb + ".1.bias"), act=ACT_RELU)]))
-        ops.append(GemmOp(h2, pw.w(bb + ".2.weight"), rh, 4, d, [seg(self.delta, 0, 4, ldo=4, bias=pw.f(bb + ".2.bias"))]))
-        ops.append(GemmOp(hs2, pw.w("class_embed.weight"), rh, self.ncls, d, [
-            seg(self.logits, 0, self.ncls, ldo=self.ldc, bias=pw.f("class_embed.bias"))]))
+        if chain_plain and self.ncls <= 1024:
+            # class_embed and the bbox_embed MLP on the hidden states of all decoder layers: one launch
+            ops.append(row_chain("heads", hs2, d, d, rh, [
+                dict(kind="side", w="class_embed.weight", b="class_embed.bias", out=self.logits, ldo=self.ldc),
+                dict(kind="full", w=bb + ".0.weight", b=bb + ".0.bias", relu=True),
+                dict(kind="full", w=bb + ".1.weight", b=bb + ".1.bias", relu=True),
+                dict(kind="side", w=bb + ".2.weight", b=bb + ".2.bias", out=self.delta, ldo=4)]))
+        else:
+            ops.append(GemmOp(hs2, pw.w(bb + ".0.weight"), rh, d, d, [seg(h1, 0, d, ldo=d, bias=pw.f(bb + ".0.bias"), act=ACT_RELU)]))
+            ops.append(GemmOp(h1, pw.w(bb + ".1.weight"), rh, d, d, [seg(h2, 0, d, ldo=d, bias=pw.f(bb + ".1.bias"), act=ACT_RELU)]))
+            ops.append(GemmOp(h2, pw.w(bb + ".2.weight"), rh, 4, d, [seg(self.delta, 0, 4, ldo=4, bias=pw.f(bb + ".2.bias"))]))
+            ops.append(GemmOp(hs2, pw.w("class_embed.weight"), rh, self.ncls, d, [
+                seg(self.logits, 0, self.ncls, ldo=self.ldc, bias=pw.f("class_embed.bias"))]))
         self.query_feat = pw.w("query_feat.weight", lambda w_: w_[:nq], "g0")
         self.refpoint = pw.f("refpoint_embed.weight", lambda w_: w_[:nq], "g0")
         # ---- fused glue launches (gather of the selected rows, decoder inputs, final boxes)

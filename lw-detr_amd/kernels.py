@@ -454,6 +454,85 @@ class EncChainOp:
             _nat.check(rc, "enc_chain")
 
 
+def row_chain_supported(d, dtype, k_in=None, res=False, qpos=False) -> bool:
+    """Shapes lwdetr_row_chain is instantiated for (LWDETR_CHAIN=0 switches every chain off)."""
+    if os.environ.get("LWDETR_CHAIN") == "0" or dtype not in (torch.float16, torch.bfloat16):
+        return False
+    k_in = k_in or d
+    if d == 256:
+        return (k_in == d and (res or not qpos)) or (k_in == 2 * d and not res and not qpos)
+    return d == 384 and k_in == d and not res and not qpos
+
+
+class RowChainOp:
+    """A chain of Linear stages over rows in one launch (lwdetr_row_chain). ``stages``: list of dicts
+      dict(kind="full", w (D, K), b (D), relu=False, res=False, ln=(gamma, beta, eps) | None, out=tensor | None, ldo=None, addq=False)
+      dict(kind="side", w (n, D), b (n), out=tensor, ldo)
+    f32 master weights; the packed stream / vectors are built here (cached by the caller through ``packed=``)."""
+
+    @staticmethod
+    def pack(d, dtype, k_in, stages):
+        perm = vb_kslot_channels(d)
+        natural = True                  # operand rows straight from memory until the first FULL stage hands its accumulators on
+        parts, vec = [], []
+        f = lambda t: t.detach().float().cpu()
+        for i, st in enumerate(stages):
+            w, b = f(st["w"]), f(st["b"])
+            if st["kind"] == "full":
+                k = k_in if i == 0 else d
+                assert w.shape == (d, k) and b.shape == (d,)
+                parts.append(chain_pieces(w, None if natural else perm))
+                vec.append(b)
+                if st.get("ln") is not None:
+                    vec += [f(st["ln"][0]), f(st["ln"][1])]
+                natural = False
+            else:
+                n = w.shape[0]
+                nt = (n + 31) // 32
+                assert w.shape[1] == d and b.shape == (n,)
+                wp = torch.zeros(32 * nt, d); wp[:n] = w
+                bp = torch.zeros(32 * nt); bp[:n] = b
+                parts.append(chain_pieces(wp, None if natural else perm))
+                vec.append(bp)
+        parts.append(torch.zeros(2 * 2048))
+        vec = torch.cat(vec)
+        nvec = (vec.numel() * 4 + 4095) // 4096 * 4096 // 4
+        return torch.cat(parts).to(dtype).contiguous(), torch.cat([vec, torch.zeros(nvec - vec.numel())]).contiguous()
+
+    def __init__(self, inp, ld_in, k_in, stages, stream, vec, *, M, d, res=None, ld_res=0, qpos=None, ld_q=0):
+        assert stream.dtype == inp.dtype and vec.dtype == torch.float32 and len(stages) <= 6
+        desc = _nat.ChainDesc()
+        desc.inp, desc.ld_in, desc.k_in = _ptr(inp), ld_in, k_in
+        desc.res, desc.ld_res, desc.qpos, desc.ld_q = _ptr(res), ld_res, _ptr(qpos), ld_q
+        desc.wstream, desc.vec, desc.M, desc.D, desc.nst = _ptr(stream), _ptr(vec), M, d, len(stages)
+        keep = [inp, res, qpos, stream, vec]
+        for i, st in enumerate(stages):
+            s = desc.st[i]
+            if st["kind"] == "full":
+                s.kind, s.n = _nat.CHAIN_FULL, d
+                ln = st.get("ln")
+                s.flags = ((_nat.CHAIN_RES if st.get("res") else 0) | (_nat.CHAIN_RELU if st.get("relu") else 0) | (_nat.CHAIN_LN if ln is not None else 0) |
+                           (_nat.CHAIN_STORE if st.get("out") is not None else 0) | (_nat.CHAIN_ADDQ if st.get("addq") else 0))
+                s.eps = float(ln[2]) if ln is not None else 0.0
+                if st.get("out") is not None:
+                    s.out, s.ldo = _ptr(st["out"]), st.get("ldo") or d
+                    keep.append(st["out"])
+            else:
+                s.kind, s.n, s.flags, s.eps = _nat.CHAIN_SIDE, st["w"].shape[0] if "w" in st else st["n"], 0, 0.0
+                s.out, s.ldo = _ptr(st["out"]), st["ldo"]
+                keep.append(st["out"])
+        lib = _nat.lib()
+        assert stream.numel() * 2 == lib.lwdetr_row_chain_pieces(C.byref(desc)) * 4096, "row chain: stream size"
+        assert vec.numel() == lib.lwdetr_row_chain_vec_floats(C.byref(desc)), "row chain: vec size"
+        self.desc, self.dtype, self._keep = desc, _nat.dtype_code(inp.dtype), keep
+        self._fn, self._ref = lib.lwdetr_row_chain, C.byref(desc)
+
+    def __call__(self, stream=None):
+        rc = self._fn(self._ref, self.dtype, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "row_chain")
+
+
 class RawOp:
     """Generic pre-bound launch: ``fn(*args, stream)`` of the C ABI (keeps the tensors behind the pointers alive)."""
 

@@ -73,3 +73,82 @@ def test_enc_chain_matches_torch(d, k5, dtype, B, npix):
     assert (clso[:, ncls:] == 0).all()
     # the row maximum is the maximum of the kernel's own (rounded) class logits, exactly
     assert torch.equal(cmax, clso[:, :ncls].float().max(1).values)
+
+
+def _run_row_chain(d, dtype, k_in, M, stages, res=None, qpos=None, x=None):
+    """stages as RowChainOp takes them (f32 masters, outputs allocated here) -> (op outputs dict, reference outputs dict)."""
+    dev = lambda t: None if t is None else t.to(DEV)
+    T = lambda t: t.to(dtype).float()
+    outs, refs = {}, {}
+    cur = x.float()
+    for i, st in enumerate(stages):
+        w16 = st["w"].to(dtype).float()
+        if st["kind"] == "full":
+            y = cur @ w16.T + st["b"]
+            if st.get("res"):
+                y = y + res.float()
+            if st.get("relu"):
+                y = y.relu()
+            y = T(y)
+            if st.get("ln") is not None:
+                y = T(_ln(y, st["ln"][0], st["ln"][1], st["ln"][2]))
+            if st.get("store"):
+                st["out"] = torch.full((M, d), 7.0, dtype=dtype, device=DEV)
+                outs[i], refs[i] = st["out"], y
+            cur = T(y + qpos.float()) if st.get("addq") else y
+        else:
+            n = st["w"].shape[0]
+            st["out"] = torch.full((M, st["ldo"]), 7.0, dtype=dtype, device=DEV)
+            outs[i], refs[i] = st["out"], T(cur @ w16.T + st["b"])
+    stream, vec = K.RowChainOp.pack(d, dtype, k_in, stages)
+    op = K.RowChainOp(dev(x), x.shape[1], k_in, stages, dev(stream), dev(vec), M=M, d=d, res=dev(res), ld_res=d if res is not None else 0,
+                      qpos=dev(qpos), ld_q=d if qpos is not None else 0)
+    op._hold = (stream, vec)
+    op()
+    torch.cuda.synchronize()
+    return outs, refs
+
+
+@pytest.mark.parametrize("name,d,dtype,M", [("front", 256, torch.float16, 4800), ("front", 256, torch.bfloat16, 300), ("back", 256, torch.float16, 1111),
+                                            ("heads", 256, torch.bfloat16, 900), ("heads", 384, torch.float16, 14400), ("bbox", 384, torch.bfloat16, 300),
+                                            ("refpoint", 256, torch.float16, 2500)])
+def test_row_chain_matches_torch(name, d, dtype, M):
+    g = torch.Generator().manual_seed(M + d)
+    r = lambda *s: torch.randn(*s, generator=g)
+    lin = lambda n, k: (r(n, k) / (k ** 0.5), r(n) * 0.3)
+    lnp = lambda eps: (1 + 0.1 * r(d), 0.1 * r(d), eps)
+    res = qpos = None
+    k_in = d
+    if name == "front":
+        w, b = lin(d, d); wo, bo = lin(96, d)
+        res, qpos = r(M, d).to(dtype), r(M, d).to(dtype)
+        stages = [dict(kind="full", w=w, b=b, res=True, ln=lnp(1e-5), store=True, addq=True), dict(kind="side", w=wo, b=bo, ldo=96)]
+    elif name == "back":
+        w, b = lin(d, d)
+        res = r(M, d).to(dtype)
+        stages = [dict(kind="full", w=w, b=b, res=True, ln=lnp(1e-5), store=True)]
+    elif name == "heads":
+        wc, bc = lin(91, d); w0, b0 = lin(d, d); w1, b1 = lin(d, d); w2, b2 = lin(4, d)
+        stages = [dict(kind="side", w=wc, b=bc, ldo=92), dict(kind="full", w=w0, b=b0, relu=True), dict(kind="full", w=w1, b=b1, relu=True),
+                  dict(kind="side", w=w2, b=b2, ldo=4)]
+    elif name == "bbox":
+        w0, b0 = lin(d, d); w1, b1 = lin(d, d); w2, b2 = lin(4, d)
+        stages = [dict(kind="full", w=w0, b=b0, relu=True), dict(kind="full", w=w1, b=b1, relu=True), dict(kind="side", w=w2, b=b2, ldo=4)]
+    else:
+        k_in = 2 * d
+        w0, b0 = lin(d, k_in); w1, b1 = lin(d, d)
+        stages = [dict(kind="full", w=w0, b=b0, relu=True), dict(kind="full", w=w1, b=b1, store=True)]
+    x = r(M, k_in).to(dtype)
+    outs, refs = _run_row_chain(d, dtype, k_in, M, stages, res=res, qpos=qpos, x=x)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert outs
+    for i in outs:
+        got, ref = outs[i].float().cpu(), refs[i]
+        n = ref.shape[1]
+        err = (got[:, :n] - ref).abs()
+        k = 3.0 + 2.0 * i                          # rounding differences compound along the chain
+        bound = k * ulp * ref.abs().clamp(min=0.25)
+        frac = (err > bound).float().mean().item()
+        assert frac < 3e-3 and err.max().item() < 16 * k * ulp * max(1.0, ref.abs().max().item()), (name, i, frac, err.max().item())
+        if got.shape[1] > (n + 3) // 4 * 4:
+            assert (got[:, (n + 3) // 4 * 4:] == 7.0).all(), "columns beyond ceil4(n) must not be written"
