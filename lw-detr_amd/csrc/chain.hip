@@ -618,6 +618,285 @@ int dispatch_enc(const EncParams& p, int D, int k5, hipStream_t st) {
     return LWDETR_ERR_UNSUPPORTED;
 }
 
+// ---- the same program, output channels split over the 4 waves of a workgroup that owns 32 rows (few rows: decoder queries).
+// The row-per-wave form above runs all N / 32 tiles of a stage one after the other on one wave: 128 dependent MFMAs per 256 x 256
+// stage, 10 - 25 us per chain whatever the row count (profiles/r4b_*), slower than the launches it replaces when the rows do not fill
+// the chip. Here wave w computes tiles w, w + 4, ... of every stage; the operand of a stage lives in LDS as B fragments (every wave
+// reads all of it into registers at the start of the stage), LayerNorm statistics go through LDS (two passes, as the row kernel),
+// and the result is written back as the fragments (2 n, 2 n + 1) of tile n - the accumulator hand-over of the row-per-wave form,
+// through LDS. Same packed weight stream, same vectors, same rounding points.
+template <typename T, int D>
+__global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainParams p) {
+    typedef typename Vec<T>::v8 V8;
+    constexpr int KS = D / 16, NTI = D / 32, PPT = D / 64, TPW = NTI / 4;     // tiles per wave and FULL stage
+    constexpr int NSLOT = 32;
+    static_assert(NTI % 4 == 0, "tiles split evenly over 4 waves");
+    static_assert(2 * 4 * PPT <= NSLOT, "the ring holds two groups of 4 tiles (a group's pieces are issued one group ahead)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int vec_b = p.vec_dpw * 4096;
+    const float* vec = (const float*)(smem + NSLOT * CH_PIECE_B);
+    char* act = smem + NSLOT * CH_PIECE_B + vec_b;                              // KS fragments of 1 KB: the current operand
+    float* stats = (float*)(act + KS * 1024);                                   // [4 waves][32 rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    const long mrow = (long)blockIdx.x * 32 + j;
+    const bool live = mrow < p.M;
+
+    // ---- prologue: input rows -> B fragments t = wave, wave + 4, ... in LDS; residual / qpos rows of this wave's tiles in registers
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+    const unsigned in_off = live ? (unsigned)(mrow * p.ld_in * 2) : 0x80000000u;
+    cu32x4 xi[KS / 4];
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i) xi[i] = __builtin_amdgcn_raw_buffer_load_b128(r_in, in_off + (unsigned)((16 * (wave + 4 * i) + 8 * h) * 2), 0, 0);
+    cu32x4 xr[TPW][2], xq[TPW][2];
+    const bool has_r = p.res != nullptr, has_q = p.qpos != nullptr;
+    {
+        const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(has_r ? (void*)p.res : (void*)p.in, 0, has_r ? (int)p.res_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_q = __builtin_amdgcn_make_buffer_rsrc(has_q ? (void*)p.qpos : (void*)p.in, 0, has_q ? (int)p.q_bytes : 0, 0x00020000);
+        const unsigned offr = live ? (unsigned)(mrow * p.ld_res * 2) : 0x80000000u, offq = live ? (unsigned)(mrow * p.ld_q * 2) : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const unsigned c = (unsigned)((32 * (wave + 4 * i) + 16 * jb + 8 * h) * 2);
+                xr[i][jb] = __builtin_amdgcn_raw_buffer_load_b128(r_res, offr + c, 0, 0);       // out of range (no residual): zeros
+                xq[i][jb] = __builtin_amdgcn_raw_buffer_load_b128(r_q, offq + c, 0, 0);
+            }
+    }
+    WRing<NSLOT> ring;
+    ring.src = (const char*)p.wstream; ring.lds0 = lds0; ring.np = p.np; ring.issued = 0; ring.wave = wave; ring.lane16 = lane16;
+    {
+        const char* vsrc = (const char*)p.vec;
+        for (int i = 0; i < p.vec_dpw; ++i) {
+            const unsigned kb = (unsigned)(wave * p.vec_dpw + i) * 1024u;
+            ring.dma1k(vsrc, kb + lane16, lds0 + NSLOT * CH_PIECE_B + kb);
+        }
+        ring.fill(NSLOT);
+    }
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i) *(cu32x4*)(act + (wave + 4 * i) * 1024 + lane16) = xi[i];
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): residual / qpos rows are in registers before the stage loop (no waits in it)
+
+    auto frag = [&](int g) -> V8 { return *(const V8*)(smem + (((unsigned)g & (NSLOT * 4 - 1)) << 10) + lane16); };
+    auto bias16 = [&](const float* src) -> f32x16 {
+        f32x16 r;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 v = *(const f32x4*)(src + 8 * b + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[4 * b + e] = v[e];
+        }
+        return r;
+    };
+    // group of up to 4 tiles (one per wave) starting at piece a, n pieces: all of them have landed, everybody is done with the pieces
+    // below a (and with the operand reads / writes before this point), the ring is topped up
+    auto begin_group = [&](int a, int n) {
+        __builtin_amdgcn_sched_barrier(0);
+        int b = a + n; b = b < p.np ? b : p.np;
+        const int v = ring.issued - b;
+        if (v <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else ch_wait_le(v);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int lim = a + NSLOT; lim = lim < p.np ? lim : p.np;
+        while (ring.issued < lim) { ring.dma_piece(ring.issued); ++ring.issued; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one 32-channel tile: KS fragments from piece `pc0` against the operand registers
+    auto tile = [&](const V8 (&x)[KS], int pc0, f32x16 acc) -> f32x16 {
+        const int g0 = 4 * pc0;
+        V8 fr[CH_RD];
+#pragma unroll
+        for (int i = 0; i < CH_RD; ++i) fr[i] = frag(g0 + i);
+#pragma unroll
+        for (int f = 0; f < KS; ++f) {
+            const V8 a = fr[f % CH_RD];
+            if (f + CH_RD < KS) fr[f % CH_RD] = frag(g0 + f + CH_RD);
+            acc = Mma32c<T>::k16(a, x[f], acc);
+        }
+        return acc;
+    };
+    auto add_own = [&](f32x16& init, const cu32x4 (&rows)[2]) {      // rows in accumulator layout (16-byte pieces) -> this lane's registers
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const cu32x4 own = crows8(rows[jb][0], rows[jb][1], rows[jb][2], rows[jb][3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned ow_ = own[q];
+                float v0, v1; cunpack2<T>(ow_, v0, v1);
+                init[8 * jb + 2 * q] += v0; init[8 * jb + 2 * q + 1] += v1;
+            }
+        }
+    };
+    int pc = 0;
+#pragma unroll 1
+    for (int si = 0; si < p.nst; ++si) {
+        // static indices + scalar selects: a run-time index (or a struct assigned in a switch) makes hipcc keep the stage table in scratch
+#define CH_STF(f) (si == 0 ? p.st[0].f : si == 1 ? p.st[1].f : si == 2 ? p.st[2].f : si == 3 ? p.st[3].f : si == 4 ? p.st[4].f : p.st[5].f)
+        struct { int kind, nt, flags, ncols, bias_off, gam_off, bet_off; float eps; void* out; long ldo; unsigned out_bytes; } st;
+        st.kind = CH_STF(kind); st.nt = CH_STF(nt); st.flags = CH_STF(flags); st.ncols = CH_STF(ncols); st.bias_off = CH_STF(bias_off);
+        st.gam_off = CH_STF(gam_off); st.bet_off = CH_STF(bet_off); st.eps = CH_STF(eps); st.out = CH_STF(out); st.ldo = CH_STF(ldo);
+        st.out_bytes = CH_STF(out_bytes);
+#undef CH_STF
+        const float* bsrc = vec + st.bias_off;
+        if (st.kind == CS_SIDE) {
+            const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(st.out, 0, (int)st.out_bytes, 0x00020000);
+            const unsigned ooff = live ? (unsigned)(mrow * st.ldo * 2) : 0x80000000u;
+            const bool wide = (st.ldo % 8 == 0) && (st.ncols % 8 == 0);
+            V8 xf[KS];
+            bool have = false;
+#pragma unroll 1
+            for (int g0t = 0; g0t < st.nt; g0t += 4) {
+                const int ng = st.nt - g0t < 4 ? st.nt - g0t : 4;
+                begin_group(pc, ng * PPT);
+                if (!have) {
+#pragma unroll
+                    for (int t = 0; t < KS; ++t) xf[t] = *(const V8*)(act + t * 1024 + lane16);
+                    have = true;
+                }
+                const int vt = g0t + wave;
+                if (wave < ng) {
+                    const f32x16 acc = tile(xf, pc + wave * PPT, bias16(bsrc + 32 * vt));
+                    unsigned w[8];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) w[d] = cpack2<T>(acc[2 * d], acc[2 * d + 1]);
+                    if (wide) {
+#pragma unroll
+                        for (int jb = 0; jb < 2; ++jb) {
+                            const cu32x4 ow = crows8(w[4 * jb], w[4 * jb + 1], w[4 * jb + 2], w[4 * jb + 3]);
+                            const int c0 = 32 * vt + 16 * jb + 8 * h;
+                            __builtin_amdgcn_raw_buffer_store_b128(ow, r_out, c0 < st.ncols ? ooff + (unsigned)(c0 * 2) : 0x80000000u, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int c0 = 32 * vt + 8 * b + 4 * h;
+                            typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
+                            __builtin_amdgcn_raw_buffer_store_b64(cu32x2{w[2 * b], w[2 * b + 1]}, r_out, c0 < st.ncols ? ooff + (unsigned)(c0 * 2) : 0x80000000u, 0, 0);
+                        }
+                    }
+                }
+                pc += ng * PPT;
+            }
+            continue;
+        }
+        // ---- FULL stage
+        const bool relu = st.flags & CF_RELU, use_r = st.flags & CF_RES, ln = st.flags & CF_LN, store = st.flags & CF_STORE, addq = st.flags & CF_ADDQ;
+        unsigned xp[TPW][8];
+        float s = 0.f;
+        {
+            V8 xf[KS];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                begin_group(pc, 4 * PPT);
+                if (i == 0) {
+#pragma unroll
+                    for (int t = 0; t < KS; ++t) xf[t] = *(const V8*)(act + t * 1024 + lane16);
+                }
+                const int n = wave + 4 * i;
+                f32x16 init = bias16(bsrc + 32 * n);
+                if (use_r) add_own(init, xr[i]);
+                const f32x16 acc = tile(xf, pc + wave * PPT, init);
+                pc += 4 * PPT;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    float a0 = acc[2 * d], a1 = acc[2 * d + 1];
+                    if (relu) { a0 = fmaxf(a0, 0.f); a1 = fmaxf(a1, 0.f); }
+                    const unsigned w = cpack2<T>(a0, a1);
+                    xp[i][d] = w;
+                    float v0, v1; cunpack2<T>(w, v0, v1);
+                    s += v0 + v1;
+                }
+            }
+        }
+        float mean = 0.f, rstd = 1.f;
+        if (ln) {       // two passes over the rounded row, partial sums of the 4 waves through LDS
+            s += __shfl_xor(s, 32);
+            if (h == 0) stats[wave * 32 + j] = s;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mean = (stats[j] + stats[32 + j] + stats[64 + j] + stats[96 + j]) * (1.f / D);
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    float v0, v1; cunpack2<T>(xp[i][d], v0, v1);
+                    v0 -= mean; v1 -= mean;
+                    v = fmaf(v0, v0, v); v = fmaf(v1, v1, v);
+                }
+            v += __shfl_xor(v, 32);
+            if (h == 0) stats[128 + wave * 32 + j] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            rstd = 1.f / sqrtf((stats[128 + j] + stats[160 + j] + stats[192 + j] + stats[224 + j]) * (1.f / D) + st.eps);
+        }
+        // every wave has read the operand into registers long ago (two group barriers back at least: TPW >= 2): overwrite it
+        const float* gam = vec + st.gam_off; const float* bet = vec + st.bet_off;
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(store ? st.out : (void*)p.in, 0, store ? (int)st.out_bytes : 0, 0x00020000);
+        const unsigned ooff = live ? (unsigned)(mrow * st.ldo * 2) : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int n = wave + 4 * i;
+            unsigned w[8];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c0 = 32 * n + 8 * b + 4 * h;
+                if (ln) {
+                    const f32x4 g = *(const f32x4*)(gam + c0), be = *(const f32x4*)(bet + c0);
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        float v0, v1; cunpack2<T>(xp[i][2 * b + d], v0, v1);
+                        w[2 * b + d] = cpack2<T>(fmaf((v0 - mean) * rstd, g[2 * d], be[2 * d]), fmaf((v1 - mean) * rstd, g[2 * d + 1], be[2 * d + 1]));
+                    }
+                } else {
+                    w[2 * b] = xp[i][2 * b]; w[2 * b + 1] = xp[i][2 * b + 1];
+                }
+            }
+            if (store) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const cu32x4 ow = crows8(w[4 * jb], w[4 * jb + 1], w[4 * jb + 2], w[4 * jb + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(ow, r_out, ooff + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+                }
+            }
+            if (addq) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const cu32x4 own = crows8(xq[i][jb][0], xq[i][jb][1], xq[i][jb][2], xq[i][jb][3]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned qw = own[q];
+                        float q0, q1, v0, v1; cunpack2<T>(qw, q0, q1); cunpack2<T>(w[4 * jb + q], v0, v1);
+                        w[4 * jb + q] = cpack2<T>(v0 + q0, v1 + q1);
+                    }
+                }
+            }
+            *(cu32x4*)(act + (2 * n) * 1024 + lane16) = cu32x4{w[0], w[1], w[2], w[3]};
+            *(cu32x4*)(act + (2 * n + 1) * 1024 + lane16) = cu32x4{w[4], w[5], w[6], w[7]};
+        }
+    }
+}
+
+template <typename T, int D>
+int launch_mlp_chain_split(const MlpChainParams& p, hipStream_t st, double flops, double bytes) {
+    const size_t lds = (size_t)32 * CH_PIECE_B + (size_t)p.vec_dpw * 4096 + (D / 16) * 1024 + 1024;
+    if (lds > 160 * 1024) return LWDETR_ERR_UNSUPPORTED;
+    static size_t attr_done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (attr_done[dev] < lds) {
+        if (hipFuncSetAttribute((const void*)mlp_chain_split_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done[dev] = 160 * 1024;
+    }
+    ProfScope ps(KID_CHAIN, flops, bytes, st);
+    hipLaunchKernelGGL((mlp_chain_split_kernel<T, D>), dim3((unsigned)((p.M + 31) / 32)), dim3(256), lds, st, p);
+    return lwdetr_check_launch();
+}
+
 template <typename T, int D, int KS0, bool RES, bool QP>
 int launch_mlp_chain(const MlpChainParams& p, hipStream_t st, double flops, double bytes) {
     constexpr size_t lds = (size_t)32 * CH_PIECE_B + CH_VEC_MAX_B;
@@ -727,6 +1006,15 @@ extern "C" int lwdetr_row_chain(const lwdetr_chain_desc* d, int dtype, void* hip
     if (uses_q) bytes += (double)d->M * d->D * 2.0;
     hipStream_t st = (hipStream_t)hip_stream;
     const bool res = d->res != nullptr, qp = d->qpos != nullptr;
+    // few rows: the channel-split form (32 rows per workgroup); many rows (or a 2 D-deep first stage): a wave per 32 rows
+    static const char* env_split = getenv("LWDETR_CHAIN_SPLIT_ROWS");
+    const long split_rows = env_split ? atol(env_split) : 65536;
+    if (d->k_in == d->D && d->M <= split_rows) {
+        int rc = LWDETR_ERR_UNSUPPORTED;
+        // (D = 384: a group of 4 tiles is 24 pieces, two of them do not fit the 32-slot ring: the row-per-wave form below)
+        if (d->D == 256) rc = dtype == DT_F16 ? launch_mlp_chain_split<f16, 256>(p, st, flops, bytes) : dtype == DT_BF16 ? launch_mlp_chain_split<bf16, 256>(p, st, flops, bytes) : rc;
+        if (rc != LWDETR_ERR_UNSUPPORTED) return rc;
+    }
     if (d->D == 256) {
         if (dtype == DT_F16) return dispatch_mlp_chain<f16, 256>(p, d->k_in, res, qp, st, flops, bytes);
         if (dtype == DT_BF16) return dispatch_mlp_chain<bf16, 256>(p, d->k_in, res, qp, st, flops, bytes);

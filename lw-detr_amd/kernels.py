@@ -459,9 +459,14 @@ def row_chain_supported(d, dtype, k_in=None, res=False, qpos=False) -> bool:
     if os.environ.get("LWDETR_CHAIN") == "0" or dtype not in (torch.float16, torch.bfloat16):
         return False
     k_in = k_in or d
-    if d == 256:
-        return (k_in == d and (res or not qpos)) or (k_in == 2 * d and not res and not qpos)
-    return d == 384 and k_in == d and not res and not qpos
+    # the launch plan uses the chains where the channel-split form exists (d = 256, k_in = d): 32 rows per workgroup. The row-per-wave
+    # form (also d = 384, k_in = 2 d; LWDETR_CHAIN_ALL=1) runs 128 dependent MFMAs per stage on one wave: slower than the launches it
+    # replaces unless the rows fill the chip several times (profiles/r4b_row_chain_forms.txt)
+    if d == 256 and k_in == d:
+        return res or not qpos
+    if os.environ.get("LWDETR_CHAIN_ALL") == "1":
+        return (d == 256 and k_in == 2 * d and not res and not qpos) or (d == 384 and k_in == d and not res and not qpos)
+    return False
 
 
 class RowChainOp:
