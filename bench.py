@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="also report p50/p90 single-image latency (bs=1); on by default at N=1")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-image latency measurement")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations (N=1 default workload only)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-cores", default="", help=argparse.SUPPRESS)
@@ -221,6 +222,75 @@ def launch_check(rank, world):
     torch.distributed.destroy_process_group()
 
 
+# The other BASELINE configurations as one GPU sees them (BASELINE.json configs 3-5: the per-GPU shard of the 8-GPU ones) + tiny:
+# measured after the timed region of the default workload and reported under "other_configs" of the same JSON line.
+OTHER_CONFIGS = [("tiny", 32, 640, "fp16"), ("medium", 64, 640, "bf16"), ("large", 32, 640, "fp16"), ("xlarge", 16, 960, "fp16")]
+
+
+def run_other_config(size, batch, res, dtype, dev, steps=20, warmup=3):
+    """{img_s, ms_per_step, dominant kernel + roofline fraction, bs=1 p50 (HIP graph)} of one more configuration: same step as the
+    default workload (forward + PostProcess on a resident synthetic batch, launch chains as LWDETR.detect chooses them)."""
+    from lwdetr_amd.models import lwdetr as _lw
+    T = DTYPES[dtype]
+    cfg = lwdetr_amd.get_args(size)
+    model, _, post = lwdetr_amd.build_model(cfg)
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=0))
+    model = model.to(dev).to(T).eval()
+    pp = post["bbox"]
+    images = synth_images(batch, res, res, seed=1234).to(dev).to(T)
+    sizes = torch.tensor([[480.0, 640.0]] * batch, device=dev)
+    for _ in range(warmup):
+        model.detect(images, sizes, pp)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _o, det = model.detect(images, sizes, pp)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(det).all()
+    out = {"workload": f"LW-DETR-{size} {res}x{res} batch {batch} {dtype}", "img_s": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "launch_chains": type(model)._chains_for(batch)}
+    gf = GFLOP_PER_IMAGE.get((size, res))
+    if gf:
+        out["model_mfma_frac"] = round(out["img_s"] * gf / 1e3 / PEAK_TFLOPS[dtype], 4)
+    before = _lw._STREAMS
+    try:                                    # per-kernel HIP events, one launch chain (see the roofline pass of the default workload)
+        _lw.set_streams(1)
+        model.detect(images, sizes, pp)
+        torch.cuda.synchronize(dev)
+        _native.prof_enable(True)
+        for _ in range(2):
+            model.detect(images, sizes, pp)
+        torch.cuda.synchronize(dev)
+        prof = _native.prof_collect()
+    finally:
+        _native.prof_enable(False)
+        _lw.set_streams(before)
+    tot = sum(v["ms"] for v in prof.values())
+    name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms, fl, by = v["ms"] / v["count"], v["flops"] / v["count"], v["bytes"] / v["count"]
+    ridge = PEAK_TFLOPS[dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    mfma = fl > 0 and fl / max(by, 1.0) >= ridge
+    ach = fl / (avg_ms * 1e-3) / 1e12 if mfma else by / (avg_ms * 1e-3) / 1e9
+    out["dominant_kernel"] = {"kernel": name, "share": round(v["ms"] / tot, 3), "avg_launch_us": round(avg_ms * 1e3, 1), "bound": "mfma" if mfma else "hbm",
+                              "frac": round(ach / (PEAK_TFLOPS[dtype] if mfma else PEAK_HBM_GBS), 4)}
+    one = images[:1].contiguous()
+    graphed = model.capture(one, postprocess=pp, target_sizes=sizes[:1])
+    lat = []
+    for i in range(60):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        graphed(one)
+        torch.cuda.synchronize(dev)
+        if i >= 10:
+            lat.append((time.perf_counter() - t) * 1e3)
+    lat.sort()
+    out["latency_bs1_hipgraph_ms_p50"] = round(lat[len(lat) // 2], 3)
+    del graphed, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -392,6 +462,17 @@ def main():
             result["latency_bs1_hipgraph_ms"] = p50p90(lambda: graphed(one))
         except Exception as e:                                   # report, never hide: the eager number above stands
             result["latency_bs1_hipgraph_ms"] = {"error": repr(e)[:200]}
+
+    default_workload = (a.size, a.batch, a.res, a.dtype) == ("small", 32, 640, "fp16")
+    if rank == 0 and world == 1 and default_workload and not a.no_other_configs:
+        # the other BASELINE configurations (and tiny) on this GPU, 20 steps each: config 3 as stated, configs 4 / 5 as the per-GPU shard
+        result["other_configs"] = {}
+        for (sz, bt, rs, dt_) in OTHER_CONFIGS:
+            log(f"other config: {sz} B={bt} {rs} {dt_}")
+            try:
+                result["other_configs"][f"{sz}_b{bt}_{rs}_{dt_}"] = run_other_config(sz, bt, rs, dt_, dev)
+            except Exception as e:                                   # never let the extra measurement cost the bench line
+                result["other_configs"][f"{sz}_b{bt}_{rs}_{dt_}"] = {"error": repr(e)[:200]}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("cpu baseline (child process)")

@@ -17,6 +17,19 @@
 #include <cstdlib>
 #include <cstring>
 
+// Phase timing for tuning (tools/chain_timing.py builds a private copy with -DLWDETR_CH_TIMING; never in the product library):
+// s_memrealtime stamps (10 ns ticks) of every wave of the first and the last workgroup of lwdetr_enc_chain at the stage boundaries,
+// plus the time spent in the ring waits and barriers.
+#ifdef LWDETR_CH_TIMING
+__device__ unsigned long long g_ch_timing[2][4][16];
+#define CH_TS(i) do { if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) g_ch_timing[blockIdx.x != 0][wave][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int lwdetr_debug_ch_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_timing), sizeof(g_ch_timing)) == hipSuccess ? 0 : 1;
+}
+#else
+#define CH_TS(i) do {} while (0)
+#endif
+
 namespace {
 
 template <typename T> struct Mma32c;
@@ -98,6 +111,61 @@ struct WRing {
         while (issued < lim) { dma_piece(issued); ++issued; }
         __builtin_amdgcn_sched_barrier(0);
     }
+
+    // ---- exact form (enc_chain_kernel; measured with the form above: 0.4 us of every 0.8 us tile in begin_tile - the counted wait
+    // took the tile epilogues' stores for prefetches still in flight, and four DMA issues of ~80 cycles each sat in front of the MFMAs;
+    // profiles/r4c_enc_chain_phase_timing.txt). Every vector-memory operation of the wave gets a sequence number; seq_of[slot] is the
+    // number of the DMA that filled the slot, so "piece q has landed" is vmcnt <= vmseq - seq_of[q]: stores never count as prefetches.
+    // The refill of the freed slots is handed out one DMA per few MFMAs (issue_one) instead of a burst.
+    int vmseq, need, lim; unsigned seq_lds;
+#ifdef LWDETR_CH_TIMING
+    unsigned long long tt_wait = 0, tt_bar = 0;
+#endif
+    __device__ __forceinline__ void seq_init(unsigned table_lds_byte_offset) {      // after a vmcnt(0): everything issued so far has landed
+        vmseq = 0; need = 0; lim = issued; seq_lds = table_lds_byte_offset;
+        for (int i = 0; i < NSLOT; ++i) *(__attribute__((address_space(3))) int*)(uintptr_t)(seq_lds + 4 * i) = 0;
+    }
+    __device__ __forceinline__ void issue_one() {
+        if (issued < lim) {
+            dma_piece(issued);
+            ++vmseq;
+            *(__attribute__((address_space(3))) int*)(uintptr_t)(seq_lds + 4 * ((unsigned)issued % NSLOT)) = vmseq;
+            ++issued;
+        }
+    }
+    __device__ __forceinline__ void flush() { while (issued < lim) issue_one(); }
+    __device__ __forceinline__ void stores(int k) { vmseq += k; }      // k vector stores issued by this wave (never more than were issued)
+    // n_next: pieces of the tile after this one (its wait count is fetched now)
+    __device__ __forceinline__ void begin_tile_x(int a, int n, int n_next) {
+        __builtin_amdgcn_sched_barrier(0);
+        flush();
+#ifdef LWDETR_CH_TIMING
+        const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
+#endif
+        int allowed = vmseq - need;                  // operations issued after the DMA of the last piece this tile reads ahead into
+        allowed = allowed > 60 ? 60 : allowed & ~3;  // rounded down: a smaller branch tree
+        switch (allowed >> 2) {
+#define CH_C(N) case N: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * N) : "memory"); break;
+            CH_C(1) CH_C(2) CH_C(3) CH_C(4) CH_C(5) CH_C(6) CH_C(7) CH_C(8) CH_C(9) CH_C(10) CH_C(11) CH_C(12) CH_C(13) CH_C(14) CH_C(15)
+#undef CH_C
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        // (no lgkmcnt wait: the fragment reads of the slots that are about to be freed have all been consumed by MFMAs in front of the
+        // sched_barrier above; the reads still in flight are the read-ahead into this tile's pieces)
+#ifdef LWDETR_CH_TIMING
+        const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef LWDETR_CH_TIMING
+        tt_wait += tb - ta; tt_bar += __builtin_amdgcn_s_memrealtime() - tb;
+#endif
+        lim = a + NSLOT; lim = lim < np ? lim : np;
+        int q = a + n + n_next + 1; q = q < np - 1 ? q : np - 1;       // last piece the NEXT tile needs (issued already: NSLOT >= 2 n + n_next + 2)
+        need = *(__attribute__((address_space(3))) const int*)(uintptr_t)(seq_lds + 4 * ((unsigned)q % NSLOT));
+        flush();                 // refill the freed slots (handing the DMAs out between the MFMAs instead measured slower: each issue
+                                 // stalls the instruction stream ~110 cycles wherever it sits)
+        __builtin_amdgcn_sched_barrier(0);
+    }
 };
 
 struct EncParams {
@@ -125,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
     constexpr int NCT = 3;                          // class tiles (ncls <= 96)
     constexpr int VEC_F = (PF ? 3 * D : 0) + 3 * D + 32 * NCT + 6 * D;
     constexpr int VEC_B = (VEC_F * 4 + 4095) / 4096 * 4096, VEC_DPW = VEC_B / 4096;
+    constexpr bool TWO_CHAINS = D == 256 && !PF;    // second accumulator chain per tile where the registers allow it (hipcc spills otherwise)
     static_assert(KS % CH_RD == 0 && KSI % CH_RD == 0, "the fragment read-ahead ring must divide every tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const float* vec = (const float*)(smem + NSLOT * CH_PIECE_B);
@@ -140,6 +209,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
     const long t0 = ((long)blockIdx.x * 4 + wave) * 32;
     const long mrow = t0 + j;
     const bool live = mrow < p.M;
+    CH_TS(0);
     // memory-space row of this lane's token
     const long img = live ? mrow / p.npix : 0;
     const long mm = live ? img * p.S + p.lsi + (mrow - img * p.npix) : 0;
@@ -164,11 +234,13 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         }
         // only the pieces of the first tile (+ read-ahead + a few) now: the first begin_tile tops the ring up. The compiler waits for
         // the input rows with a vmcnt that does not know of the DMAs: every DMA issued before that wait would have to land first.
-        ring.fill((PF ? PPT5 : PPT) + 2 + 4);
+        ring.fill(2 * (PF ? PPT5 : PPT) + 2);            // (begin_tile_x: the first tile fetches the wait count of the second)
     }
     // an explicit vmcnt(0) the compiler can see (a real S_WAITCNT, not inline assembly): hipcc's own waits for the input rows and flags
     // are satisfied HERE, before the ring fill of the first begin_tile, and it adds none behind it
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    ring.seq_init(lds0 + NSLOT * CH_PIECE_B + VEC_B + (unsigned)wave * NSLOT * 4);
+    CH_TS(1);
     auto frag = [&](int g) -> V8 {           // global fragment index g = 4 * piece + fragment
         return *(const V8*)(smem + (((unsigned)g & (NSLOT * 4 - 1)) << 10) + lane16);
     };
@@ -190,17 +262,31 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
 
     int pc = 0;                                  // next piece
     V8 fr[CH_RD];
+#ifdef LWDETR_CH_TIMING
+    unsigned long long tt_mfma = 0, tt_epi = 0;
+#endif
     // 32 channels x 32 rows: nf fragments against x[0 .. nf), fragment stream position 4 * pc
     auto tile = [&](auto& x, auto nf_tag, f32x16 acc) -> f32x16 {
         constexpr int nf = decltype(nf_tag)::value;
         const int g0 = 4 * pc;
+        // two independent accumulator chains (even / odd k-steps): a 32x32x16 MFMA that accumulates into the result of the one right
+        // in front of it waits for that result
+        f32x16 acc2 = {};
 #pragma unroll
         for (int f = 0; f < nf; ++f) {
             const V8 a = fr[f % CH_RD];
             fr[f % CH_RD] = frag(g0 + f + CH_RD);
-            acc = Mma32c<T>::k16(a, x[f], acc);
+            if (TWO_CHAINS && (f & 1)) acc2 = Mma32c<T>::k16(a, x[f], acc2);
+            else acc = Mma32c<T>::k16(a, x[f], acc);
+            // pin the order: hipcc otherwise sinks every fragment read to just in front of its MFMA (each MFMA then waits a whole LDS
+            // round trip: 114 - 139 cycles per MFMA slot measured, profiles/r4c_enc_chain_phase_timing.txt)
+            __builtin_amdgcn_sched_barrier(0);
         }
         pc += nf / 4;
+        if (TWO_CHAINS) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
+        }
         return acc;
     };
     // rows rounded to T held as packed pairs (dword d of tile n = registers 2 d, 2 d + 1): LayerNorm with affine, stores the
@@ -241,20 +327,22 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
             xo[2 * n] = __builtin_bit_cast(V8, cu32x4{w[0], w[1], w[2], w[3]});
             xo[2 * n + 1] = __builtin_bit_cast(V8, cu32x4{w[4], w[5], w[6], w[7]});
         }
+        ring.stores(2 * NTI);
     };
 
     V8 xf[KS];                                   // `memory` rows as B operands
     // first tile: its pieces (and the two read ahead) have landed; the read-ahead ring starts
-    ring.template begin_tile<4>(0, PF ? PPT5 : PPT);
+    ring.begin_tile_x(0, PF ? PPT5 : PPT, PF ? PPT5 : PPT);
 #pragma unroll
     for (int i = 0; i < CH_RD; ++i) fr[i] = frag(i);
+    CH_TS(2);
     if constexpr (PF) {
         // ---- projector: C2f.cv2 (1x1 conv, BatchNorm folded) + SiLU, LayerNorm over channels -> memory (projector.py:117-132)
         unsigned xp[NTI][8];
         float s = 0.f;
 #pragma unroll
         for (int n = 0; n < NTI; ++n) {
-            if (n > 0) ring.template begin_tile<NSLOT - 2 * PPT5 - 2>(pc, PPT5);
+            if (n > 0) ring.begin_tile_x(pc, PPT5, n + 1 < NTI ? PPT5 : PPT);
             const f32x16 acc = tile(xin, std::integral_constant<int, KSI>{}, bias16(b2s + 32 * n));
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
@@ -270,13 +358,21 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
 #pragma unroll
         for (int t = 0; t < KS; ++t) xf[t] = xin[t];
     }
+    CH_TS(3);
     // ---- value projections of all decoder layers (ms_deform_attn.py:110-114: masked_fill of the OUTPUT rows of padded pixels)
     {
         const int nvt = p.nl * NTI;
 #pragma unroll 1
         for (int vt = 0; vt < nvt; ++vt) {
-            if (PF || vt > 0) ring.template begin_tile<NSLOT - 2 * PPT - 2>(pc, PPT);
+            if (PF || vt > 0) ring.begin_tile_x(pc, PPT, PPT);
+#ifdef LWDETR_CH_TIMING
+            const unsigned long long tv0 = __builtin_amdgcn_s_memrealtime();
+#endif
             f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bvs + 32 * vt));
+#ifdef LWDETR_CH_TIMING
+            asm volatile("" : "+v"(acc));
+            const unsigned long long tv1 = __builtin_amdgcn_s_memrealtime();
+#endif
             const int li = vt / NTI, n = vt - li * NTI;
             const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(p.values[li], 0, (int)p.mem_bytes, 0x00020000);
             if (!npd) {
@@ -289,8 +385,13 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
                                          cpack2<T>(acc[8 * jb + 4], acc[8 * jb + 5]), cpack2<T>(acc[8 * jb + 6], acc[8 * jb + 7]));
                 __builtin_amdgcn_raw_buffer_store_b128(ow, r_v, row_off + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
             }
+            ring.stores(2);
+#ifdef LWDETR_CH_TIMING
+            tt_mfma += tv1 - tv0; tt_epi += __builtin_amdgcn_s_memrealtime() - tv1;
+#endif
         }
     }
+    CH_TS(4);
     // ---- enc_output Linear on the rows (invalid proposals: the INPUT row is zeroed, transformer.py:113-116) + LayerNorm -> output_memory
     {
         if (!rv) {
@@ -301,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         float s = 0.f;
 #pragma unroll
         for (int n = 0; n < NTI; ++n) {
-            ring.template begin_tile<NSLOT - 2 * PPT - 2>(pc, PPT);
+            ring.begin_tile_x(pc, PPT, PPT);
             const f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bes + 32 * n));
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
@@ -313,12 +414,13 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
         }
         layernorm_store(xp, s, ges, bts, p.eps_e, r_om, xf);
     }
+    CH_TS(5);
     // ---- class logits of every token and their maximum (the two-stage selection score, transformer.py:244-246)
     {
         float mx = -INFINITY;
 #pragma unroll
         for (int n = 0; n < NCT; ++n) {
-            ring.template begin_tile<NSLOT - 2 * PPT - 2>(pc, PPT);
+            ring.begin_tile_x(pc, PPT, PPT);
             const f32x16 acc = tile(xf, std::integral_constant<int, KS>{}, bias16(bcs + 32 * n));
             unsigned w[8];
 #pragma unroll
@@ -334,10 +436,16 @@ __global__ __launch_bounds__(256, 1) void enc_chain_kernel(const EncParams p) {
                 const cu32x4 ow = crows8(w[4 * jb], w[4 * jb + 1], w[4 * jb + 2], w[4 * jb + 3]);
                 __builtin_amdgcn_raw_buffer_store_b128(ow, r_cls, cls_off + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
             }
+            ring.stores(2);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         if (live && h == 0) p.cls_max[mm] = mx;
     }
+    CH_TS(6);
+#ifdef LWDETR_CH_TIMING
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) { g_ch_timing[blockIdx.x != 0][wave][13] = ring.tt_wait; g_ch_timing[blockIdx.x != 0][wave][14] = ring.tt_bar;
+        g_ch_timing[blockIdx.x != 0][wave][11] = tt_mfma; g_ch_timing[blockIdx.x != 0][wave][12] = tt_epi; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ generic row chain
@@ -364,6 +472,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const MlpChainParams 
     typedef typename Vec<T>::v8 V8;
     constexpr int KS = D / 16, NTI = D / 32, PPT = D / 64, PPT0 = KS0 / 4;
     constexpr int NSLOT = 32;
+    constexpr bool TWO_CHAINS = false;              // (registers: the rolled stage loop of this form is at the limit already)
     static_assert(KS % CH_RD == 0 && KS0 % CH_RD == 0, "the fragment read-ahead ring must divide every tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const float* vec = (const float*)(smem + NSLOT * CH_PIECE_B);
@@ -428,13 +537,24 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const MlpChainParams 
     auto tile = [&](auto& x, auto nf_tag, f32x16 acc) -> f32x16 {
         constexpr int nf = decltype(nf_tag)::value;
         const int g0 = 4 * pc;
+        // two independent accumulator chains (even / odd k-steps): a 32x32x16 MFMA that accumulates into the result of the one right
+        // in front of it waits for that result
+        f32x16 acc2 = {};
 #pragma unroll
         for (int f = 0; f < nf; ++f) {
             const V8 a = fr[f % CH_RD];
             fr[f % CH_RD] = frag(g0 + f + CH_RD);
-            acc = Mma32c<T>::k16(a, x[f], acc);
+            if (TWO_CHAINS && (f & 1)) acc2 = Mma32c<T>::k16(a, x[f], acc2);
+            else acc = Mma32c<T>::k16(a, x[f], acc);
+            // pin the order: hipcc otherwise sinks every fragment read to just in front of its MFMA (each MFMA then waits a whole LDS
+            // round trip: 114 - 139 cycles per MFMA slot measured, profiles/r4c_enc_chain_phase_timing.txt)
+            __builtin_amdgcn_sched_barrier(0);
         }
         pc += nf / 4;
+        if (TWO_CHAINS) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
+        }
         return acc;
     };
     auto next_tile = [&](int n) {
@@ -593,7 +713,7 @@ int launch_enc(const EncParams& p, hipStream_t st) {
     constexpr int NSLOT = 32, NCT = 3;
     constexpr int VEC_F = (PF ? 3 * D : 0) + 3 * D + 32 * NCT + 6 * D;
     constexpr int VEC_B = (VEC_F * 4 + 4095) / 4096 * 4096;
-    constexpr size_t lds = (size_t)NSLOT * CH_PIECE_B + VEC_B;
+    constexpr size_t lds = (size_t)NSLOT * CH_PIECE_B + VEC_B + 4 * NSLOT * 4;      // ring, vectors, sequence numbers of the 4 waves
     static bool attr_done[16] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
@@ -710,12 +830,17 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainP
         V8 fr[CH_RD];
 #pragma unroll
         for (int i = 0; i < CH_RD; ++i) fr[i] = frag(g0 + i);
+        f32x16 acc2 = {};                       // two independent accumulator chains (even / odd k-steps)
 #pragma unroll
         for (int f = 0; f < KS; ++f) {
             const V8 a = fr[f % CH_RD];
             if (f + CH_RD < KS) fr[f % CH_RD] = frag(g0 + f + CH_RD);
-            acc = Mma32c<T>::k16(a, x[f], acc);
+            if (f & 1) acc2 = Mma32c<T>::k16(a, x[f], acc2);
+            else acc = Mma32c<T>::k16(a, x[f], acc);
+            __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads CH_RD MFMAs ahead (see enc_chain_kernel)
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
         return acc;
     };
     auto add_own = [&](f32x16& init, const cu32x4 (&rows)[2]) {      // rows in accumulator layout (16-byte pieces) -> this lane's registers
@@ -1008,7 +1133,7 @@ extern "C" int lwdetr_row_chain(const lwdetr_chain_desc* d, int dtype, void* hip
     const bool res = d->res != nullptr, qp = d->qpos != nullptr;
     // few rows: the channel-split form (32 rows per workgroup); many rows (or a 2 D-deep first stage): a wave per 32 rows
     static const char* env_split = getenv("LWDETR_CHAIN_SPLIT_ROWS");
-    const long split_rows = env_split ? atol(env_split) : 65536;
+    const long split_rows = env_split ? atol(env_split) : 12288;      // <= 384 workgroups of 32 rows (1.5 rounds of one per CU)
     if (d->k_in == d->D && d->M <= split_rows) {
         int rc = LWDETR_ERR_UNSUPPORTED;
         // (D = 384: a group of 4 tiles is 24 pieces, two of them do not fit the 32-slot ring: the row-per-wave form below)
