@@ -20,6 +20,12 @@ def bench_name(k):
     """rocprof kernel symbol -> bench.py / prof.hip kernel class (None = not one of ours)."""
     if "vitblock_kernel" in k:
         return "vit_block"
+    if "enc_chain_kernel" in k:
+        return "row_chain_enc"
+    if "mlp_chain_split_kernel" in k:
+        return "row_chain_split"
+    if "mlp_chain_kernel" in k:
+        return "row_chain_rowwave"
     if "mlp_kernel" in k or "mlp_small_kernel" in k:
         return "mlp_fused"
     if "attn_lds_kernel" in k:

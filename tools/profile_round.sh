@@ -17,12 +17,12 @@ KEEP=$OUT/keep_$TAG
 mkdir -p "$KEEP"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --no-latency "$@" > "$KEEP/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/prof_${TAG}_bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$TAG" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --no-latency --no-other-configs "$@" > "$KEEP/${TAG}_bench_under_rocprofv3.json" 2> "$OUT/prof_${TAG}_bench.err"
 find "$OUT/prof_$TAG" -name "*kernel_stats.csv" -exec cp {} "$KEEP/${TAG}_kernel_stats.csv" \;
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_${TAG}_$i" -o b -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-latency "$@" > /dev/null 2> "$OUT/pmc_${TAG}_$i.err"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_${TAG}_$i" -o b -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-latency --no-other-configs "$@" > /dev/null 2> "$OUT/pmc_${TAG}_$i.err"
 done
 cd "$ROOT"
 python tools/pmc_summary.py "$KEEP/${TAG}_kernel_stats.csv" "$OUT"/pmc_${TAG}_[1-5] > "$KEEP/${TAG}_pmc_summary.json"
