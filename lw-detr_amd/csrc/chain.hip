@@ -749,9 +749,12 @@ template <typename T, int D>
 __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainParams p) {
     typedef typename Vec<T>::v8 V8;
     constexpr int KS = D / 16, NTI = D / 32, PPT = D / 64, TPW = NTI / 4;     // tiles per wave and FULL stage
-    constexpr int NSLOT = 32;
-    static_assert(NTI % 4 == 0, "tiles split evenly over 4 waves");
-    static_assert(2 * 4 * PPT <= NSLOT, "the ring holds two groups of 4 tiles (a group's pieces are issued one group ahead)");
+    // A step = the pieces of up to 4 tiles (one per wave) that land together. D = 256: a tile's 4 pieces; D = 384: HALF a tile's 6 pieces
+    // (the stream is packed k-half-major inside a group of 4 tiles, lwdetr_amd/kernels.py:chain_pieces_split): two steps fit the ring
+    constexpr int HALVES = D == 384 ? 2 : 1, PPH = PPT / HALVES, KSH = KS / HALVES;
+    constexpr int NSLOT = D == 384 ? 24 : 32;
+    static_assert(NTI % 4 == 0 && PPT % HALVES == 0, "tiles split evenly over 4 waves");
+    static_assert(2 * 4 * PPH <= NSLOT, "the ring holds two steps (a step's pieces are issued one step ahead)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int vec_b = p.vec_dpw * 4096;
     const float* vec = (const float*)(smem + NSLOT * CH_PIECE_B);
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainP
     for (int i = 0; i < KS / 4; ++i) *(cu32x4*)(act + (wave + 4 * i) * 1024 + lane16) = xi[i];
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): residual / qpos rows are in registers before the stage loop (no waits in it)
 
-    auto frag = [&](int g) -> V8 { return *(const V8*)(smem + (((unsigned)g & (NSLOT * 4 - 1)) << 10) + lane16); };
+    auto frag = [&](int g) -> V8 { return *(const V8*)(smem + (((unsigned)g % (NSLOT * 4)) << 10) + lane16); };
     auto bias16 = [&](const float* src) -> f32x16 {
         f32x16 r;
 #pragma unroll
@@ -824,19 +827,20 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainP
         while (ring.issued < lim) { ring.dma_piece(ring.issued); ++ring.issued; }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // one 32-channel tile: KS fragments from piece `pc0` against the operand registers
-    auto tile = [&](const V8 (&x)[KS], int pc0, f32x16 acc) -> f32x16 {
+    // one step of a 32-channel tile: KSH fragments from piece `pc0` against the operand registers x[x0 .. x0 + KSH)
+    auto tile = [&](const V8 (&x)[KS], auto x0_tag, int pc0, f32x16 acc) -> f32x16 {
+        constexpr int x0 = decltype(x0_tag)::value;
         const int g0 = 4 * pc0;
         V8 fr[CH_RD];
 #pragma unroll
         for (int i = 0; i < CH_RD; ++i) fr[i] = frag(g0 + i);
         f32x16 acc2 = {};                       // two independent accumulator chains (even / odd k-steps)
 #pragma unroll
-        for (int f = 0; f < KS; ++f) {
+        for (int f = 0; f < KSH; ++f) {
             const V8 a = fr[f % CH_RD];
-            if (f + CH_RD < KS) fr[f % CH_RD] = frag(g0 + f + CH_RD);
-            if (f & 1) acc2 = Mma32c<T>::k16(a, x[f], acc2);
-            else acc = Mma32c<T>::k16(a, x[f], acc);
+            if (f + CH_RD < KSH) fr[f % CH_RD] = frag(g0 + f + CH_RD);
+            if (f & 1) acc2 = Mma32c<T>::k16(a, x[x0 + f], acc2);
+            else acc = Mma32c<T>::k16(a, x[x0 + f], acc);
             __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads CH_RD MFMAs ahead (see enc_chain_kernel)
         }
 #pragma unroll
@@ -875,15 +879,22 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainP
 #pragma unroll 1
             for (int g0t = 0; g0t < st.nt; g0t += 4) {
                 const int ng = st.nt - g0t < 4 ? st.nt - g0t : 4;
-                begin_group(pc, ng * PPT);
+                const int vt = g0t + wave;
+                f32x16 acc = bias16(bsrc + 32 * (vt < st.nt ? vt : 0));
+                begin_group(pc, ng * PPH);
                 if (!have) {
 #pragma unroll
                     for (int t = 0; t < KS; ++t) xf[t] = *(const V8*)(act + t * 1024 + lane16);
                     have = true;
                 }
-                const int vt = g0t + wave;
+                if (wave < ng) acc = tile(xf, std::integral_constant<int, 0>{}, pc + wave * PPH, acc);
+                pc += ng * PPH;
+                if constexpr (HALVES == 2) {
+                    begin_group(pc, ng * PPH);
+                    if (wave < ng) acc = tile(xf, std::integral_constant<int, KSH>{}, pc + wave * PPH, acc);
+                    pc += ng * PPH;
+                }
                 if (wave < ng) {
-                    const f32x16 acc = tile(xf, pc + wave * PPT, bias16(bsrc + 32 * vt));
                     unsigned w[8];
 #pragma unroll
                     for (int d = 0; d < 8; ++d) w[d] = cpack2<T>(acc[2 * d], acc[2 * d + 1]);
@@ -903,7 +914,6 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainP
                         }
                     }
                 }
-                pc += ng * PPT;
             }
             continue;
         }
@@ -915,16 +925,21 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainP
             V8 xf[KS];
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                begin_group(pc, 4 * PPT);
+                const int n = wave + 4 * i;
+                f32x16 acc = bias16(bsrc + 32 * n);
+                if (use_r) add_own(acc, xr[i]);
+                begin_group(pc, 4 * PPH);
                 if (i == 0) {
 #pragma unroll
                     for (int t = 0; t < KS; ++t) xf[t] = *(const V8*)(act + t * 1024 + lane16);
                 }
-                const int n = wave + 4 * i;
-                f32x16 init = bias16(bsrc + 32 * n);
-                if (use_r) add_own(init, xr[i]);
-                const f32x16 acc = tile(xf, pc + wave * PPT, init);
-                pc += 4 * PPT;
+                acc = tile(xf, std::integral_constant<int, 0>{}, pc + wave * PPH, acc);
+                pc += 4 * PPH;
+                if constexpr (HALVES == 2) {
+                    begin_group(pc, 4 * PPH);
+                    acc = tile(xf, std::integral_constant<int, KSH>{}, pc + wave * PPH, acc);
+                    pc += 4 * PPH;
+                }
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
                     float a0 = acc[2 * d], a1 = acc[2 * d + 1];
@@ -1007,7 +1022,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_split_kernel(const MlpChainP
 
 template <typename T, int D>
 int launch_mlp_chain_split(const MlpChainParams& p, hipStream_t st, double flops, double bytes) {
-    const size_t lds = (size_t)32 * CH_PIECE_B + (size_t)p.vec_dpw * 4096 + (D / 16) * 1024 + 1024;
+    const size_t lds = (size_t)(D == 384 ? 24 : 32) * CH_PIECE_B + (size_t)p.vec_dpw * 4096 + (D / 16) * 1024 + 1024;
     if (lds > 160 * 1024) return LWDETR_ERR_UNSUPPORTED;
     static size_t attr_done[16] = {};
     int dev = 0;
@@ -1040,24 +1055,20 @@ int launch_mlp_chain(const MlpChainParams& p, hipStream_t st, double flops, doub
 
 template <typename T, int D>
 int dispatch_mlp_chain(const MlpChainParams& p, int k_in, bool res, bool qp, hipStream_t st, double flops, double bytes) {
-    // D = 384 is instantiated without residual / qpos rows only: with them the rolled stage loop needs more than the 512 registers
-    // of a lone wave (hipcc 7.2 spills 280 - 950 bytes per lane); the decoder chains of the d = 384 models stay on separate launches
-    if constexpr (D == 256) {
-        if (k_in == 2 * D) return (res || qp) ? LWDETR_ERR_UNSUPPORTED : launch_mlp_chain<T, D, D / 8, false, false>(p, st, flops, bytes);
-        if (k_in != D) return LWDETR_ERR_UNSUPPORTED;
-        if (qp) return res ? launch_mlp_chain<T, D, D / 16, true, true>(p, st, flops, bytes) : LWDETR_ERR_UNSUPPORTED;
-        return res ? launch_mlp_chain<T, D, D / 16, true, false>(p, st, flops, bytes) : launch_mlp_chain<T, D, D / 16, false, false>(p, st, flops, bytes);
-    } else {
-        if (k_in != D || res || qp) return LWDETR_ERR_UNSUPPORTED;
-        return launch_mlp_chain<T, D, D / 16, false, false>(p, st, flops, bytes);
-    }
+    // row-per-wave form: D = 256 only (at D = 384 the rolled stage loop needs more than the 512 registers of a lone wave - hipcc 7.2
+    // spills 280 - 950 bytes per lane - and the channel-split form serves every row count there)
+    static_assert(D == 256, "row-per-wave form");
+    if (k_in == 2 * D) return (res || qp) ? LWDETR_ERR_UNSUPPORTED : launch_mlp_chain<T, D, D / 8, false, false>(p, st, flops, bytes);
+    if (k_in != D) return LWDETR_ERR_UNSUPPORTED;
+    if (qp) return res ? launch_mlp_chain<T, D, D / 16, true, true>(p, st, flops, bytes) : LWDETR_ERR_UNSUPPORTED;
+    return res ? launch_mlp_chain<T, D, D / 16, true, false>(p, st, flops, bytes) : launch_mlp_chain<T, D, D / 16, false, false>(p, st, flops, bytes);
 }
 
 // vec layout / piece count of a chain description (shared by the size helpers and the launch)
 struct ChainLayout { long pieces, vec_floats; int bias_off[6], gam_off[6], bet_off[6], nt[6]; bool ok; };
 ChainLayout chain_layout(const lwdetr_chain_desc* d) {
     ChainLayout L = {};
-    if (!d || (d->D != 256 && d->D != 384) || d->nst < 1 || d->nst > 6 || (d->k_in != d->D && d->k_in != 2 * d->D)) return L;
+    if (!d || (d->D != 256 && d->D != 384) || d->nst < 1 || d->nst > 6 || (d->k_in != d->D && !(d->D == 256 && d->k_in == 2 * d->D))) return L;
     long off = 0, pieces = 0;
     for (int i = 0; i < d->nst; ++i) {
         const lwdetr_chain_stage& s = d->st[i];
@@ -1134,19 +1145,17 @@ extern "C" int lwdetr_row_chain(const lwdetr_chain_desc* d, int dtype, void* hip
     // few rows: the channel-split form (32 rows per workgroup); many rows (or a 2 D-deep first stage): a wave per 32 rows
     static const char* env_split = getenv("LWDETR_CHAIN_SPLIT_ROWS");
     const long split_rows = env_split ? atol(env_split) : 12288;      // <= 384 workgroups of 32 rows (1.5 rounds of one per CU)
+    // D = 384: only the channel-split form (its stream is packed k-half-major: the two forms cannot read each other's streams)
+    if (d->D == 384) {
+        if (d->k_in != d->D) return LWDETR_ERR_UNSUPPORTED;
+        return dtype == DT_F16 ? launch_mlp_chain_split<f16, 384>(p, st, flops, bytes) : dtype == DT_BF16 ? launch_mlp_chain_split<bf16, 384>(p, st, flops, bytes) : LWDETR_ERR_UNSUPPORTED;
+    }
     if (d->k_in == d->D && d->M <= split_rows) {
-        int rc = LWDETR_ERR_UNSUPPORTED;
-        // (D = 384: a group of 4 tiles is 24 pieces, two of them do not fit the 32-slot ring: the row-per-wave form below)
-        if (d->D == 256) rc = dtype == DT_F16 ? launch_mlp_chain_split<f16, 256>(p, st, flops, bytes) : dtype == DT_BF16 ? launch_mlp_chain_split<bf16, 256>(p, st, flops, bytes) : rc;
+        const int rc = dtype == DT_F16 ? launch_mlp_chain_split<f16, 256>(p, st, flops, bytes) : dtype == DT_BF16 ? launch_mlp_chain_split<bf16, 256>(p, st, flops, bytes) : LWDETR_ERR_UNSUPPORTED;
         if (rc != LWDETR_ERR_UNSUPPORTED) return rc;
     }
-    if (d->D == 256) {
-        if (dtype == DT_F16) return dispatch_mlp_chain<f16, 256>(p, d->k_in, res, qp, st, flops, bytes);
-        if (dtype == DT_BF16) return dispatch_mlp_chain<bf16, 256>(p, d->k_in, res, qp, st, flops, bytes);
-    } else {
-        if (dtype == DT_F16) return dispatch_mlp_chain<f16, 384>(p, d->k_in, res, qp, st, flops, bytes);
-        if (dtype == DT_BF16) return dispatch_mlp_chain<bf16, 384>(p, d->k_in, res, qp, st, flops, bytes);
-    }
+    if (dtype == DT_F16) return dispatch_mlp_chain<f16, 256>(p, d->k_in, res, qp, st, flops, bytes);
+    if (dtype == DT_BF16) return dispatch_mlp_chain<bf16, 256>(p, d->k_in, res, qp, st, flops, bytes);
     return LWDETR_ERR_UNSUPPORTED;
 }
 

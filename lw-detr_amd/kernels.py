@@ -400,6 +400,20 @@ def chain_pieces(w, kslots=None):
     return wk.reshape(n // 32, 32, k // 64, 4, 2, 8).permute(0, 2, 3, 4, 1, 5).reshape(-1)
 
 
+def chain_pieces_split(w, kslots=None):
+    """As chain_pieces for the channel-split form at K = 384 (lwdetr_row_chain, D = 384): inside every group of up to 4 tiles the pieces
+    are ordered k-half-major - first the pieces [0, 3) of every tile of the group, then the pieces [3, 6) - because a step of that
+    kernel is HALF a tile per wave (two steps of 4 x 3 pieces fit its 24-slot ring; 4 whole tiles = 24 pieces would not)."""
+    n, k = w.shape
+    assert n % 32 == 0 and k == 384
+    t = chain_pieces(w, kslots).reshape(n // 32, 6, 2048)                 # tile, piece, elements
+    out = []
+    for g0 in range(0, n // 32, 4):
+        grp = t[g0:g0 + 4]
+        out += [grp[:, :3].reshape(-1), grp[:, 3:].reshape(-1)]
+    return torch.cat(out)
+
+
 def pack_enc_chain(d, dtype, w_enc, b_enc, g_enc, be_enc, w_cls, b_cls, w_val, b_val, cv2=None):
     """Host-side packing for lwdetr_enc_chain (f32 master tensors in) -> (stream of ``dtype``, vec f32).
     cv2 = (w2 (d, k5) BatchNorm-folded, b2 (d), ln_w (d), ln_b (d)) or None. Consumption order: cv2 | values | enc_output | class | 2 zero
@@ -459,14 +473,15 @@ def row_chain_supported(d, dtype, k_in=None, res=False, qpos=False) -> bool:
     if os.environ.get("LWDETR_CHAIN") == "0" or dtype not in (torch.float16, torch.bfloat16):
         return False
     k_in = k_in or d
-    # the launch plan uses the chains where the channel-split form exists (d = 256, k_in = d): 32 rows per workgroup. The row-per-wave
-    # form (also d = 384, k_in = 2 d; LWDETR_CHAIN_ALL=1) runs 128 dependent MFMAs per stage on one wave: slower than the launches it
-    # replaces unless the rows fill the chip several times (profiles/r4b_row_chain_forms.txt)
-    if d == 256 and k_in == d:
+    # The launch plan uses the chains at d = 256, k_in = d (channel-split form, 32 rows per workgroup: bs=1 0.925 -> 0.872 ms, B = 32
+    # +3.8 % on LW-DETR-small). Implemented and tested but NOT in the plan (LWDETR_CHAIN_ALL=1 enables them): d = 384 - a step of the
+    # split form is half a tile per wave there (12 MFMAs between two ring waits): out_proj + LN + offsets 49.6 vs 43.1 us as separate
+    # launches, LW-DETR-large B = 32 4.15 k vs 4.39 k img/s, bs=1 unchanged; k_in = 2 d (ref_point_head) only exists in the row-per-wave
+    # form, which runs 128 dependent MFMAs per stage on one wave (profiles/r4b_row_chain_forms.txt).
+    all_forms = os.environ.get("LWDETR_CHAIN_ALL") == "1"
+    if k_in == d and (d == 256 or (d == 384 and all_forms)):
         return res or not qpos
-    if os.environ.get("LWDETR_CHAIN_ALL") == "1":
-        return (d == 256 and k_in == 2 * d and not res and not qpos) or (d == 384 and k_in == d and not res and not qpos)
-    return False
+    return all_forms and d == 256 and k_in == 2 * d and not res and not qpos
 
 
 class RowChainOp:
@@ -481,12 +496,13 @@ class RowChainOp:
         natural = True                  # operand rows straight from memory until the first FULL stage hands its accumulators on
         parts, vec = [], []
         f = lambda t: t.detach().float().cpu()
+        pieces = chain_pieces_split if d == 384 else chain_pieces      # d = 384: only the channel-split form exists (k-half-major stream)
         for i, st in enumerate(stages):
             w, b = f(st["w"]), f(st["b"])
             if st["kind"] == "full":
                 k = k_in if i == 0 else d
                 assert w.shape == (d, k) and b.shape == (d,)
-                parts.append(chain_pieces(w, None if natural else perm))
+                parts.append(pieces(w, None if natural else perm))
                 vec.append(b)
                 if st.get("ln") is not None:
                     vec += [f(st["ln"][0]), f(st["ln"][1])]
@@ -497,7 +513,7 @@ class RowChainOp:
                 assert w.shape[1] == d and b.shape == (n,)
                 wp = torch.zeros(32 * nt, d); wp[:n] = w
                 bp = torch.zeros(32 * nt); bp[:n] = b
-                parts.append(chain_pieces(wp, None if natural else perm))
+                parts.append(pieces(wp, None if natural else perm))
                 vec.append(bp)
         parts.append(torch.zeros(2 * 2048))
         vec = torch.cat(vec)

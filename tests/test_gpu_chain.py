@@ -111,6 +111,7 @@ def _run_row_chain(d, dtype, k_in, M, stages, res=None, qpos=None, x=None):
 
 @pytest.mark.parametrize("name,d,dtype,M", [("front", 256, torch.float16, 4800), ("front", 256, torch.bfloat16, 300), ("back", 256, torch.float16, 1111),
                                             ("heads", 256, torch.bfloat16, 900), ("heads", 384, torch.float16, 14400), ("bbox", 384, torch.bfloat16, 300),
+                                            ("front", 384, torch.float16, 9600), ("back", 384, torch.bfloat16, 301), ("front", 384, torch.bfloat16, 33),
                                             ("refpoint", 256, torch.float16, 2500),
                                             # more than 12 288 rows: the row-per-wave form (fewer: 32-row workgroups, channels split over the waves)
                                             ("front", 256, torch.float16, 14400), ("heads", 256, torch.bfloat16, 28800)])
@@ -122,9 +123,10 @@ def test_row_chain_matches_torch(name, d, dtype, M):
     res = qpos = None
     k_in = d
     if name == "front":
-        w, b = lin(d, d); wo, bo = lin(96, d)
+        noa = 96 if d == 256 else 576                  # sampling_offsets | attention_weights: heads * levels * points * 3
+        w, b = lin(d, d); wo, bo = lin(noa, d)
         res, qpos = r(M, d).to(dtype), r(M, d).to(dtype)
-        stages = [dict(kind="full", w=w, b=b, res=True, ln=lnp(1e-5), store=True, addq=True), dict(kind="side", w=wo, b=bo, ldo=96)]
+        stages = [dict(kind="full", w=w, b=b, res=True, ln=lnp(1e-5), store=True, addq=True), dict(kind="side", w=wo, b=bo, ldo=noa)]
     elif name == "back":
         w, b = lin(d, d)
         res = r(M, d).to(dtype)
