@@ -90,3 +90,86 @@ def simulate_enc_wave(stream, vec, rows_in, rowvalid, notpad, D, k5, nl, ncls, e
     out["cls_max"] = cls[:, :ncls].max(1)
     out["fragments_consumed"] = g[0]
     return out
+
+
+def simulate_row_chain_split(stream, vec, stages, x_rows, res_rows, q_rows, D):
+    """One 32-row workgroup of lw-detr_amd/csrc/chain.hip:mlp_chain_split_kernel (4 waves, wave w computes tiles w, w + 4, ... of every
+    stage; at D = 384 a tile is two k-half steps and the stream is packed k-half-major inside a group of 4 tiles). stages: dicts with
+    kind ("full" | "side"), n (side: columns), flags res / relu / ln (eps) / addq. Returns the list of per-stage outputs (32, N).
+    float64, no rounding: validates RowChainOp.pack and the kernel's piece / fragment / hand-over arithmetic."""
+    KS, NTI, PPT = D // 16, D // 32, D // 64
+    HALVES = 2 if D == 384 else 1
+    PPH, KSH = PPT // HALVES, KS // HALVES
+    frags = np.asarray(stream, dtype=np.float64).reshape(-1, 64, 8)
+    vec = np.asarray(vec, dtype=np.float64)
+    lanes = np.arange(64); J, H = lanes & 31, lanes >> 5
+
+    def chan(n, r):
+        return 32 * n + 8 * (r // 4) + 4 * H + (r % 4)
+
+    def bias16(src):
+        out = np.zeros((64, 16))
+        for r in range(16):
+            out[:, r] = src[8 * (r // 4) + 4 * H + (r % 4)]
+        return out
+
+    def own_rows(mat, n):             # rows in accumulator layout of tile n
+        out = np.zeros((64, 16))
+        for r in range(16):
+            out[:, r] = mat[J, chan(n, r)]
+        return out
+
+    # operand in "LDS": KS fragments, natural k order at the start
+    act = [np.stack([x_rows[J[l], 16 * t + 8 * H[l]:16 * t + 8 * H[l] + 8] for l in range(64)]) for t in range(KS)]
+    pc, off, outs = 0, 0, []
+
+    def run_tile(xf, pc0, x0, acc):
+        for f in range(KSH):
+            acc = mfma_32x32x16(frags[4 * pc0 + f], xf[x0 + f], acc)
+        return acc
+
+    for st in stages:
+        if st["kind"] == "side":
+            nt = (st["n"] + 31) // 32
+            bsrc = vec[off:off + 32 * nt]; off += 32 * nt
+            res_out = np.zeros((32, 32 * nt))
+            for g0 in range(0, nt, 4):
+                ng = min(4, nt - g0)
+                accs = {w: bias16(bsrc[32 * (g0 + w):32 * (g0 + w) + 32]) for w in range(ng)}
+                for hf in range(HALVES):
+                    for w in range(ng):
+                        accs[w] = run_tile(act, pc + w * PPH, hf * KSH, accs[w])
+                    pc += ng * PPH
+                for w in range(ng):
+                    for r in range(16):
+                        res_out[J, chan(g0 + w, r)] = accs[w][:, r]
+            outs.append(res_out[:, :st["n"]])
+            continue
+        bsrc = vec[off:off + D]; off += D
+        if st.get("ln") is not None:
+            gam, bet = vec[off:off + D], vec[off + D:off + 2 * D]; off += 2 * D
+        tiles = {}
+        for i in range(NTI // 4):
+            accs = {}
+            for w in range(4):
+                n = w + 4 * i
+                accs[w] = bias16(bsrc[32 * n:32 * n + 32]) + (own_rows(res_rows, n) if st.get("res") else 0.0)
+            for hf in range(HALVES):
+                for w in range(4):
+                    accs[w] = run_tile(act, pc + w * PPH, hf * KSH, accs[w])
+                pc += 4 * PPH
+            for w in range(4):
+                tiles[w + 4 * i] = np.maximum(accs[w], 0.0) if st.get("relu") else accs[w]
+        y = np.zeros((32, D))
+        for n in range(NTI):
+            for r in range(16):
+                y[J, chan(n, r)] = tiles[n][:, r]
+        if st.get("ln") is not None:
+            mu = y.mean(1, keepdims=True)
+            y = (y - mu) / np.sqrt(((y - mu) ** 2).mean(1, keepdims=True) + st["ln"]) * gam + bet
+        outs.append(y.copy())
+        nxt = y + q_rows if st.get("addq") else y
+        for n in range(NTI):                      # written back as the fragments (2 n, 2 n + 1) of tile n: registers 0..7 / 8..15
+            t = own_rows(nxt, n)
+            act[2 * n], act[2 * n + 1] = t[:, 0:8].copy(), t[:, 8:16].copy()
+    return outs, pc

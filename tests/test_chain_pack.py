@@ -53,3 +53,30 @@ def test_enc_chain_stream_walk_equals_dense(d, k5, nl):
     np.testing.assert_allclose(sim["cls"][:, :ncls], cls, rtol=0, atol=1e-9)
     assert np.abs(sim["cls"][:, ncls:]).max() == 0
     np.testing.assert_allclose(sim["cls_max"], cls.max(1), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("d", [256, 384])
+def test_row_chain_split_stream_walk_equals_dense(d):
+    """RowChainOp.pack walked as mlp_chain_split_kernel walks it (tiles dealt over 4 waves; d = 384: two k-half steps per tile, k-half-major
+    stream) equals the dense chain: class head from the input, out_proj + residual + LayerNorm (+ query_pos), a 100-column side stage, an MLP stage."""
+    from chain_sim import simulate_row_chain_split
+    g = torch.Generator().manual_seed(d)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float32).double()
+    n = lambda t: t.double().numpy()
+    w0, b0 = r(91, d) / 16, r(91)
+    w1, b1, g1, be1 = r(d, d) / 16, r(d), (1 + 0.125 * r(d)).float().double(), 0.125 * r(d)
+    w2, b2 = r(100, d) / 16, r(100)
+    w3, b3 = r(d, d) / 16, r(d)
+    stages = [dict(kind="side", w=w0, b=b0), dict(kind="full", w=w1, b=b1, res=True, ln=(g1, be1, 1e-5), addq=True),
+              dict(kind="side", w=w2, b=b2), dict(kind="full", w=w3, b=b3, relu=True)]
+    stream, vec = K.RowChainOp.pack(d, torch.float64, d, stages)
+    x, res, q = n(r(32, d)), n(r(32, d)), n(r(32, d))
+    sim_stages = [dict(kind="side", n=91), dict(kind="full", res=True, ln=1e-5, addq=True), dict(kind="side", n=100), dict(kind="full", relu=True)]
+    outs, pieces = simulate_row_chain_split(stream.double().numpy(), vec.double().numpy(), sim_stages, x, res, q, d)
+    assert pieces * 2048 + 2 * 2048 == stream.numel()
+    y0 = x @ n(w0).T + n(b0)
+    y1 = _ln(x @ n(w1).T + n(b1) + res, n(g1), n(be1), 1e-5)
+    y2 = (y1 + q) @ n(w2).T + n(b2)
+    y3 = np.maximum((y1 + q) @ n(w3).T + n(b3), 0.0)
+    for got, ref in zip(outs, (y0, y1, y2, y3)):
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
