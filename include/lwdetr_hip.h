@@ -247,6 +247,15 @@ long lwdetr_row_chain_pieces(const lwdetr_chain_desc* desc);
 long lwdetr_row_chain_vec_floats(const lwdetr_chain_desc* desc);
 int lwdetr_row_chain(const lwdetr_chain_desc* desc, int dtype, void* hip_stream);
 
+/* norm1 + QKV of a ViT block on its own (block 0, which has no block kernel in front of it; models/backbone/vit.py:199, :123-130):
+ * q (pre-scaled by qscale), k as (B, heads, Tp, hd), v^T as (B, heads, hd, Tp) from the rows x (M, ldx). wstream / vec:
+ * lwdetr_amd.kernels.pack_vit_qkv (3 C / 32 pieces of 32 features x C in natural k order, LayerNorm affine folded; f32 bias).
+ * C in {192, 384}, 16-bit dtypes, M % Tp == 0, Tp % 8 == 0, hd a power of two >= 8. */
+long lwdetr_vit_qkv_stream_bytes(int C);
+long lwdetr_vit_qkv_vec_floats(int C);
+int lwdetr_vit_qkv(const void* x, long ldx, const void* wstream, const float* vec, long M, int C, float eps, void* q_out,
+                   void* k_out, void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream);
+
 /* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
  * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */
 int lwdetr_select_gather(const void* om, const void* enc_cls, long ldc, const float* props, const int64_t* idx,

@@ -676,6 +676,227 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     VB_TS(11);
 }
 
+// ---------------------------------------------------------------------------------------------------- norm1 + QKV alone
+// Block 0 of the ViT has no block kernel in front of it: its norm1 + QKV (vit.py:199, :123-130) ran as a LayerNorm launch + a GEMM
+// (12 + 59 us at BASELINE config 2). This is the chained QKV phase of vitblock_kernel on its own: the wave's token rows come from
+// memory as B fragments (natural k order: the weights are packed in natural order too, kernels.py:pack_vit_qkv), LayerNorm in
+// registers (affine folded into the weights), Q / K as (B, heads, Tp, hd), V^T as (B, heads, hd, Tp).
+template <typename T, int C, int NH>
+__global__ __launch_bounds__(256, 1) void vit_qkv_kernel(const VbParams p) {
+    typedef typename Vec<T>::v8 V8;
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    constexpr int KS = C / 16, NTI = C / 32;
+    constexpr int PIECE_B = KS * 1024, DPW = KS / 4;
+    constexpr int NSLOT = C == 192 ? 8 : 5;
+    constexpr int VEC_B = (3 * C * 4 + 4095) / 4096 * 4096, VEC_DPW = VEC_B / 4096;
+    constexpr int NP = 3 * NTI;
+    constexpr int RD = NH == 2 ? 4 : 8;
+    static_assert(DPW % 3 == 0, "wait counts are kept in multiples of 3");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float* bqs = (const float*)(smem + NSLOT * PIECE_B);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    const long U = p.M >> 3, nwv = (long)gridDim.x * 4, wg = (long)blockIdx.x * 4 + wave;
+    const long u0 = wg * U / nwv, u1 = (wg + 1) * U / nwv;
+    const long t0 = u0 * 8;
+    const int nvalid = (int)(u1 - u0) * 8;
+    const char* wsrc = (const char*)p.wstream;
+    auto dma1k = [&](const char* src_uniform, unsigned voff, unsigned lds_dst) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)src_uniform);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)src_uniform >> 32));
+        const char* sp = (const char*)(((uintptr_t)hi << 32) | lo);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(sp) : "memory");
+    };
+    auto dma_piece = [&](int piece) {
+        const unsigned slot = (unsigned)piece % NSLOT;
+        const char* src = wsrc + (size_t)piece * PIECE_B;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const unsigned kb = (unsigned)(wave * DPW + i) * 1024u;
+            dma1k(src, kb + lane16, lds0 + slot * PIECE_B + kb);
+        }
+    };
+    int issued = 0;
+    auto boundary = [&](int a, int b, int extra) {
+        __builtin_amdgcn_sched_barrier(0);
+        vb_wait_le((issued - b) * DPW + extra);
+        __builtin_amdgcn_s_barrier();
+        int lim = a + NSLOT; lim = lim < NP ? lim : NP;
+        while (issued < lim) { dma_piece(issued); ++issued; }
+    };
+    auto frag = [&](int piece, int f) -> V8 { return *(const V8*)(smem + ((unsigned)piece % NSLOT) * PIECE_B + f * 1024 + lane16); };
+    {
+        const char* vsrc = (const char*)p.vec;
+#pragma unroll
+        for (int i = 0; i < VEC_DPW; ++i) {
+            const unsigned kb = (unsigned)(wave * VEC_DPW + i) * 1024u;
+            dma1k(vsrc, kb + lane16, lds0 + NSLOT * PIECE_B + kb);
+        }
+        for (; issued < NSLOT && issued < NP; ++issued) dma_piece(issued);
+    }
+    const T* x_w = (const T*)p.x + t0 * p.ldx;
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)x_w, 0, (int)(nvalid * p.ldx * 2), 0x00020000);
+    V8 xf[NH][KS];
+#pragma unroll
+    for (int th = 0; th < NH; ++th)
+#pragma unroll
+        for (int t = 0; t < KS; ++t)
+            xf[th][t] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(r_x, (unsigned)(((32 * th + j) * p.ldx + 16 * t + 8 * h) * 2), 0, 0));
+    boundary(0, 2, NH * KS);
+    // ---- LayerNorm of the rows (two passes over the registers; lanes (j, 0) and (j, 1) hold alternating 8-channel runs of token j)
+#pragma unroll
+    for (int th = 0; th < NH; ++th) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += to_f32<T>(xf[th][t][e]);
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.f / C);
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < KS; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = to_f32<T>(xf[th][t][e]) - mean; v = fmaf(dl, dl, v); }
+        v += __shfl_xor(v, 32);
+        const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps_next), nmr = -mean * rstd;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            u32x4 w;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) w[d] = pack2<T>(fmaf(to_f32<T>(xf[th][t][2 * d]), rstd, nmr), fmaf(to_f32<T>(xf[th][t][2 * d + 1]), rstd, nmr));
+            xf[th][t] = __builtin_bit_cast(V8, w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto bias16 = [&](const float* src) -> f32x16 {
+        f32x16 r;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 v = *(const f32x4*)(src + 8 * b + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[4 * b + e] = v[e];
+        }
+        return r;
+    };
+    const __amdgpu_buffer_rsrc_t r_q = __builtin_amdgcn_make_buffer_rsrc(p.q, 0, (int)p.qkv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc(p.k, 0, (int)p.qkv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(p.vt, 0, (int)p.qkv_bytes, 0x00020000);
+    const int hd = 1 << p.hd_log2;
+    unsigned row_qk[NH];
+#pragma unroll
+    for (int th = 0; th < NH; ++th) {
+        const unsigned tok = (unsigned)t0 + 32 * th + j;
+        const unsigned img = tok / (unsigned)p.Tp, wi = tok - img * (unsigned)p.Tp;
+        row_qk[th] = 32 * th + j < nvalid ? (unsigned)(((long)img * p.heads * p.Tp + wi) << p.hd_log2) : 0x7fffffffu;
+    }
+    constexpr int SPS = 2 * NH * 2, LAG = (NSLOT - 2) / 2;
+    unsigned row_v8[NH][2];
+#pragma unroll
+    for (int th = 0; th < NH; ++th)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int tl = 32 * th + 16 * jb + 8 * h;
+            const unsigned tk = (unsigned)t0 + tl;
+            const unsigned im = tk / (unsigned)p.Tp, wv = tk - im * (unsigned)p.Tp;
+            row_v8[th][jb] = tl < nvalid ? (unsigned)((long)im * p.heads * hd * p.Tp + wv) : 0x7fffffffu;
+        }
+#pragma unroll 1
+    for (int s = 0; s < NP / 2; ++s) {
+        if (s > 0) boundary(2 * s, 2 * s + 2, s < LAG ? SPS * s : SPS * LAG);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pi = 2 * s + pp, piece = pi;
+            const int sg = pi / NTI, nl0 = (pi - sg * NTI) * 32;
+            f32x16 acc[NH];
+            if (sg < 2) {
+                const f32x16 bias = bias16(bqs + sg * C + nl0);
+                V8 fr[RD];
+#pragma unroll
+                for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    const V8 a = fr[t % RD];
+#pragma unroll
+                    for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(a, xf[th][t], t == 0 ? bias : acc[th]);
+                    if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (sg == 0) {
+#pragma unroll
+                    for (int th = 0; th < NH; ++th)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[th][e] *= p.qscale;
+                }
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const int f = nl0 + 16 * jb + 8 * h, hh = f >> p.hd_log2, dd = f & (hd - 1);
+                    const unsigned col = (unsigned)(((long)hh * p.Tp << p.hd_log2) + dd);
+#pragma unroll
+                    for (int th = 0; th < NH; ++th) {
+                        const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
+                                                  pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
+                        const unsigned off = row_qk[th] == 0x7fffffffu ? 0x80000000u : (row_qk[th] + col) * 2u;
+                        if (sg == 0) __builtin_amdgcn_raw_buffer_store_b128(ow, r_q, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(ow, r_k, off, 0, 0);
+                    }
+                }
+            } else {
+                const float bv = bqs[2 * C + nl0 + j];
+                f32x16 binit;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) binit[e] = bv;
+                V8 fr[RD];
+#pragma unroll
+                for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    const V8 a = fr[t % RD];
+#pragma unroll
+                    for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(xf[th][t], a, t == 0 ? binit : acc[th]);
+                    if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int f = nl0 + j, hh = f >> p.hd_log2, dd = f & (hd - 1);
+                const unsigned rowb = (unsigned)(((long)hh * hd + dd) * p.Tp);
+#pragma unroll
+                for (int th = 0; th < NH; ++th)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
+                                                  pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
+                        const unsigned off = row_v8[th][jb] == 0x7fffffffu ? 0x80000000u : (row_v8[th][jb] + rowb) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b128(ow, r_v, off, 0, 0);
+                    }
+            }
+        }
+    }
+}
+
+template <typename T, int C, int NH>
+int launch_vq(const VbParams& p, hipStream_t st) {
+    constexpr int KS = C / 16, PIECE_B = KS * 1024, NSLOT = C == 192 ? 8 : 5;
+    constexpr int VEC_B = (3 * C * 4 + 4095) / 4096 * 4096;
+    constexpr size_t lds = (size_t)NSLOT * PIECE_B + VEC_B;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)vit_qkv_kernel<T, C, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done[dev] = true;
+    }
+    const long per_wg = 4L * 32 * NH;
+    long grid = (p.M + per_wg - 1) / per_wg;
+    while (((p.M / 8 + grid * 4 - 1) / (grid * 4)) * 8 > 32 * NH) ++grid;
+    ProfScope ps(KID_VITBLOCK, 6.0 * p.M * C * C, (double)p.M * C * sizeof(T) * 4, st);
+    hipLaunchKernelGGL((vit_qkv_kernel<T, C, NH>), dim3((unsigned)grid), dim3(256), lds, st, p);
+    return lwdetr_check_launch();
+}
+
 struct VbLaunchState { bool attr_done; int ncu; };
 
 template <typename T, int C, int NH, bool QKV>
@@ -758,4 +979,25 @@ extern "C" int lwdetr_vit_block(void* x, long ldx, const void* att, long ldatt, 
         case DT_BF16: return dispatch_vb<bf16>(p, C, has_qkv != 0, st);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" long lwdetr_vit_qkv_stream_bytes(int C) { return (C == 192 || C == 384) ? 3L * (C / 32) * (C / 16) * 1024L : -LWDETR_ERR_UNSUPPORTED; }
+extern "C" long lwdetr_vit_qkv_vec_floats(int C) { return ((3L * C * 4 + 4095) / 4096 * 4096) / 4; }
+
+extern "C" int lwdetr_vit_qkv(const void* x, long ldx, const void* wstream, const float* vec, long M, int C, float eps, void* q_out,
+                              void* k_out, void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream) {
+    if (!x || !wstream || !vec || !q_out || !k_out || !vt_out || M < 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    if (ldx % 8 != 0 || ((uintptr_t)x | (uintptr_t)wstream | (uintptr_t)vec | (uintptr_t)q_out | (uintptr_t)k_out | (uintptr_t)vt_out) % 16 != 0) return LWDETR_ERR_BAD_ARG;
+    if (heads <= 0 || hd < 8 || (hd & (hd - 1)) != 0 || heads * hd != C || Tp <= 0 || Tp % 8 != 0) return LWDETR_ERR_UNSUPPORTED;
+    if (M % 8 != 0 || M % Tp != 0 || (double)M * C * 2.0 >= 2147483000.0 || (double)ldx * 64 * 2 >= 2147483000.0) return LWDETR_ERR_UNSUPPORTED;
+    VbParams p = {};
+    p.x = (void*)x; p.ldx = ldx; p.wstream = wstream; p.vec = vec; p.M = M; p.eps_next = eps; p.qscale = qscale;
+    int l2 = 0; while ((1 << l2) < hd) ++l2;
+    p.q = q_out; p.k = k_out; p.vt = vt_out; p.heads = heads; p.hd_log2 = l2; p.Tp = Tp;
+    p.qkv_bytes = (unsigned)((unsigned long)M * C * 2ul);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (C == 192) return dtype == DT_F16 ? launch_vq<f16, 192, 2>(p, st) : dtype == DT_BF16 ? launch_vq<bf16, 192, 2>(p, st) : LWDETR_ERR_UNSUPPORTED;
+    if (C == 384) return dtype == DT_F16 ? launch_vq<f16, 384, 1>(p, st) : dtype == DT_BF16 ? launch_vq<bf16, 384, 1>(p, st) : LWDETR_ERR_UNSUPPORTED;
+    return LWDETR_ERR_UNSUPPORTED;
 }

@@ -214,7 +214,13 @@ class ForwardPlan:
         for i in range(self.depth):
             blk = f"{pre}.blocks.{i}"
             window = i in self.cfg.window_block_indexes
-            if i == 0 or not fused:
+            if i == 0 and fused and K.vit_block_supported(C, self.T, hd, rows) and rows % Tp == 0 and Tp % 8 == 0 and os.environ.get("LWDETR_VIT_QKV", "1") != "0":
+                # block 0: norm1 + QKV in one launch (the QKV phase of the block kernel on its own; round 4)
+                sq, vq = pw.custom_multi(blk + ".vitqkv.packed", lambda blk=blk: K.pack_vit_qkv(
+                    pw.sd[blk + ".attn.qkv.weight"], pw.sd[blk + ".attn.q_bias"], pw.sd[blk + ".attn.v_bias"],
+                    pw.sd[blk + ".norm1.weight"], pw.sd[blk + ".norm1.bias"], self.T))
+                ops.append(K.VitQkvOp(self.x, sq, vq, rows, C, 1e-6, q=q, k=k, vt=vt, qscale=qscale, heads=heads, hd=hd, Tp=Tp))
+            elif i == 0 or not fused:
                 # norm1 + QKV as separate launches (blocks > 0 get them chained into the previous block's MLP kernel)
                 ops.append(LayerNormOp(self.x, pw.f(blk + ".norm1.weight"), pw.f(blk + ".norm1.bias"), xn, rows, C, 1e-6))
                 ops.append(GemmOp(xn, pw.w(blk + ".attn.qkv.weight"), rows, 3 * C, C, [

@@ -353,6 +353,38 @@ def pack_vit_block(wp, bp, g1, w1, b1, w2, b2, g2, ln2_w, ln2_b, dtype, qkv=None
     return stream, vec
 
 
+def pack_vit_qkv(wqkv, q_bias, v_bias, ln_w, ln_b, dtype):
+    """Host-side packing for lwdetr_vit_qkv (norm1 + QKV of a block on its own: block 0): stream = 3 C / 32 pieces of 32 output
+    features x C in NATURAL k order (the rows come straight from memory), LayerNorm affine folded; vec = [q_bias, 0, v_bias] + W beta."""
+    f = lambda t: t.detach().float().cpu()
+    wqkv, q_bias, v_bias, ln_w, ln_b = map(f, (wqkv, q_bias, v_bias, ln_w, ln_b))
+    c = wqkv.shape[1]
+    assert c in (192, 384) and wqkv.shape[0] == 3 * c
+    bq = torch.cat([q_bias, torch.zeros_like(q_bias), v_bias]) + wqkv @ ln_b
+    wq = wqkv * ln_w[None, :]
+    stream = torch.cat([_vb_frags(wq[32 * i:32 * i + 32]).reshape(-1) for i in range(3 * c // 32)]).to(dtype).contiguous()
+    nvec = (3 * c * 4 + 4095) // 4096 * 4096 // 4
+    return stream, torch.cat([bq, torch.zeros(nvec - bq.numel())]).contiguous()
+
+
+class VitQkvOp:
+    """q, k, v^T = heads(LN(x) Wqkv^T + b): norm1 + QKV of a ViT block in one launch (lwdetr_vit_qkv)."""
+
+    def __init__(self, x, stream, vec, M, C_, eps, *, q, k, vt, qscale, heads, hd, Tp, ldx=None):
+        assert stream.dtype == x.dtype and vec.dtype == torch.float32
+        lib = _nat.lib()
+        assert stream.numel() * 2 == lib.lwdetr_vit_qkv_stream_bytes(C_) and vec.numel() == lib.lwdetr_vit_qkv_vec_floats(C_)
+        self.args = (_ptr(x), ldx if ldx is not None else C_, _ptr(stream), _ptr(vec), M, C_, float(eps), _ptr(q), _ptr(k), _ptr(vt),
+                     float(qscale), heads, hd, Tp, _nat.dtype_code(x.dtype))
+        self._keep = (x, stream, vec, q, k, vt)
+        self._fn = lib.lwdetr_vit_qkv
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "vit_qkv")
+
+
 class VitBlockOp:
     """x <- block tail (attention projection + MLP, + norm1 / QKV of the next block) in one launch (lwdetr_vit_block)."""
 

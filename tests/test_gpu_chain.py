@@ -156,3 +156,33 @@ def test_row_chain_matches_torch(name, d, dtype, M):
         assert frac < 3e-3 and err.max().item() < 16 * k * ulp * max(1.0, ref.abs().max().item()), (name, i, frac, err.max().item())
         if got.shape[1] > (n + 3) // 4 * 4:
             assert (got[:, (n + 3) // 4 * 4:] == 7.0).all(), "columns beyond ceil4(n) must not be written"
+
+
+@pytest.mark.parametrize("dtype,c,heads,m,tp", [(torch.float16, 192, 12, 51200, 1600), (torch.bfloat16, 192, 12, 12800, 1600), (torch.float16, 384, 12, 25600, 1600),
+                                                (torch.bfloat16, 384, 12, 3648 * 4, 3648), (torch.float16, 192, 12, 1600, 1600)])
+def test_vit_qkv_matches_torch(dtype, c, heads, m, tp):
+    """lwdetr_vit_qkv (norm1 + QKV of block 0 in one launch) vs LayerNorm + Linear in fp32 on the same 16-bit operands (vit.py:199, :123-130)."""
+    g = torch.Generator().manual_seed(c + m)
+    r = lambda *s: torch.randn(*s, generator=g)
+    hd = c // heads
+    x = (r(m, c) * 2 + 0.3).to(dtype)
+    wqkv, qb, vb = r(3 * c, c) / c ** 0.5, r(c) * 0.1, r(c) * 0.1
+    lw, lb = r(c) * 0.2 + 1, r(c) * 0.1
+    stream, vec = K.pack_vit_qkv(wqkv, qb, vb, lw, lb, dtype)
+    nb = m // tp
+    q = torch.full((nb, heads, tp, hd), float("nan"), dtype=dtype, device=DEV)
+    k = torch.full_like(q, float("nan"))
+    vt = torch.full((nb, heads, hd, tp), float("nan"), dtype=dtype, device=DEV)
+    K.VitQkvOp(x.to(DEV), stream.to(DEV), vec.to(DEV), m, c, 1e-6, q=q, k=k, vt=vt, qscale=0.37, heads=heads, hd=hd, Tp=tp)()
+    torch.cuda.synchronize()
+    xn = torch.nn.functional.layer_norm(x.float(), (c,), lw, lb, 1e-6)
+    ref = xn @ wqkv.t() + torch.cat([qb, torch.zeros(c), vb])
+    rq = (ref[:, :c] * 0.37).view(nb, tp, heads, hd).permute(0, 2, 1, 3)
+    rk = ref[:, c:2 * c].view(nb, tp, heads, hd).permute(0, 2, 1, 3)
+    rv = ref[:, 2 * c:].view(nb, tp, heads, hd).permute(0, 2, 3, 1)
+    tol = {torch.float16: 6e-3, torch.bfloat16: 5e-2}[dtype]
+    for got, want, name in ((q, rq, "q"), (k, rk, "k"), (vt, rv, "vt")):
+        got = got.float().cpu()
+        assert torch.isfinite(got).all(), name
+        err = (got - want).abs().max().item() / want.abs().max().item()
+        assert err < tol, (name, err)
