@@ -137,6 +137,37 @@ def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_logit, tol_box, 
     assert torch.isfinite(free["pred_logits"].float()).all()
 
 
+@pytest.mark.parametrize("name,dtype,tol_logit,tol_box", [("small_padded", torch.float16, 0.05, 0.005), ("large_padded", torch.float16, 0.09, 0.008),
+                                                          ("small_padded", torch.bfloat16, 0.4, 0.04)])
+def test_low_precision_padded_batches_through_the_row_chains(name, dtype, tol_logit, tol_box, monkeypatch):
+    """Padded NestedTensor batches in 16-bit with the round-4 chain kernels forced on (LWDETR_CHAIN=1: the golden batches are
+    below the row count from which the plan uses lwdetr_enc_chain by itself): the padding masks reach the chain as row flags
+    (invalid proposals zero the enc_output INPUT row, padded pixels zero the value OUTPUT rows) - compared with the reference
+    goldens under the teacher-forced selection, and with the same model without the chains."""
+    g = load_golden(name)
+    size, images, mask = case_batch(name)
+    forced = torch.from_numpy(g["topk_idx"]).to(DEV)
+    from lwdetr_amd.models.nested import NestedTensor
+    outs = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("LWDETR_CHAIN", chain)
+        model, _ = _model(size, golden_state_dict(g), dtype)
+        col = {}
+        outs[chain] = (model(NestedTensor(images.to(DEV).to(dtype), mask.to(DEV)), _collect=col, _forced_topk=forced), col)
+        plan = next(iter(model._plans.values()))
+        assert plan.use_chain == (chain == "1")
+    out, col = outs["1"]
+    d = _diffs(out, g)
+    assert max(d["pred_logits"], d["enc_logits"]) < tol_logit, d
+    assert max(d["pred_boxes"], d["enc_boxes"]) < tol_box, d
+    ref, col0 = outs["0"]
+    # the two launch plans agree to 16-bit noise on every stage the chain replaces
+    for k in ("memory", "om"):
+        a, b = col[k].float(), col0[k].float()
+        assert (a - b).abs().max().item() <= 0.03 * max(1.0, b.abs().max().item()) * (8 if dtype == torch.bfloat16 else 1), k
+    assert (col["enc.class_max"] - col0["enc.class_max"]).abs().max().item() < (0.5 if dtype == torch.bfloat16 else 0.06)
+
+
 def test_state_dict_roundtrip_and_reload_invalidates_cache():
     g = load_golden("tiny_192x256")
     size, images, mask = case_batch("tiny_192x256")
