@@ -20,6 +20,8 @@ def bench_name(k):
     """rocprof kernel symbol -> bench.py / prof.hip kernel class (None = not one of ours)."""
     if "vitblock_kernel" in k:
         return "vit_block"
+    if "vit_qkv_kernel" in k:
+        return "vit_qkv"
     if "enc_chain_kernel" in k:
         return "row_chain_enc"
     if "mlp_chain_split_kernel" in k:
