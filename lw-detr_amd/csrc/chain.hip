@@ -1144,7 +1144,8 @@ extern "C" int lwdetr_row_chain(const lwdetr_chain_desc* d, int dtype, void* hip
     const bool res = d->res != nullptr, qp = d->qpos != nullptr;
     // few rows: the channel-split form (32 rows per workgroup); many rows (or a 2 D-deep first stage): a wave per 32 rows
     static const char* env_split = getenv("LWDETR_CHAIN_SPLIT_ROWS");
-    const long split_rows = env_split ? atol(env_split) : 12288;      // <= 384 workgroups of 32 rows (1.5 rounds of one per CU)
+    const long split_rows = env_split ? atol(env_split) : 16384;      // <= 512 workgroups of 32 rows (two rounds of one per CU); measured: the heads chain of a
+                                                                       // 16-image launch chain (14 400 rows) is 2-3 % of the step faster in this form (profiles/r4e_*)
     // D = 384: only the channel-split form (its stream is packed k-half-major: the two forms cannot read each other's streams)
     if (d->D == 384) {
         if (d->k_in != d->D) return LWDETR_ERR_UNSUPPORTED;

@@ -113,8 +113,8 @@ def _run_row_chain(d, dtype, k_in, M, stages, res=None, qpos=None, x=None):
                                             ("heads", 256, torch.bfloat16, 900), ("heads", 384, torch.float16, 14400), ("bbox", 384, torch.bfloat16, 300),
                                             ("front", 384, torch.float16, 9600), ("back", 384, torch.bfloat16, 301), ("front", 384, torch.bfloat16, 33),
                                             ("refpoint", 256, torch.float16, 2500),
-                                            # more than 12 288 rows: the row-per-wave form (fewer: 32-row workgroups, channels split over the waves)
-                                            ("front", 256, torch.float16, 14400), ("heads", 256, torch.bfloat16, 28800)])
+                                            # more than 16 384 rows: the row-per-wave form (fewer: 32-row workgroups, channels split over the waves)
+                                            ("front", 256, torch.float16, 14400), ("front", 256, torch.float16, 19200), ("heads", 256, torch.bfloat16, 28800)])
 def test_row_chain_matches_torch(name, d, dtype, M):
     g = torch.Generator().manual_seed(M + d)
     r = lambda *s: torch.randn(*s, generator=g)
