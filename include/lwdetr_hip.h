@@ -136,6 +136,10 @@ int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* hip_stream);
 /* Kernel selection override for tests / tuning (process-wide): lds_mode -1 = default (environment LWDETR_ATTN_LDS, else 2),
  * 0 = never use the LDS-ring kernel, 1 = sequences of >= 512 keys, 2 = also >= 192-key windows, 3 = everything >= 64 keys. */
 void lwdetr_attention_tuning(int lds_mode);
+/* LDS-ring kernel shape override for tests / tuning (process-wide): 0 = default (environment LWDETR_ATTN_LDS_CFG, else by head
+ * dimension), otherwise 1000 (U - 1) + 100 QT + NW = 32 QT queries per wave, NW waves per workgroup, U 64-key blocks per ring step;
+ * a shape that is not compiled in (or does not fit LDS at this head dimension) makes lwdetr_attention return LWDETR_ERR_UNSUPPORTED. */
+void lwdetr_attention_tuning_cfg(int cfg);
 
 /* ---- row LayerNorm: out[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta; biased variance; C % 4 == 0 ------------- */
 /* rows_per_batch / out_batch_stride / out_row_offset let the projector write straight into `memory` (B,S,d). */

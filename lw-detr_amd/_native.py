@@ -90,6 +90,8 @@ def lib():
         l.lwdetr_gemm_tuning.restype = None
         l.lwdetr_attention_tuning.argtypes = [i]
         l.lwdetr_attention_tuning.restype = None
+        l.lwdetr_attention_tuning_cfg.argtypes = [i]
+        l.lwdetr_attention_tuning_cfg.restype = None
         l.lwdetr_layernorm.argtypes = [vp, lg, vp, vp, vp, lg, lg, i, f, lg, lg, lg, i, vp]
         l.lwdetr_layernorm_chain.argtypes = [vp, lg, vp, vp, f, vp, lg, vp, vp, f, vp, lg, lg, i, i, vp]
         l.lwdetr_ffn_splits.argtypes = [lg, i, i, i]

@@ -345,7 +345,7 @@ __device__ __forceinline__ void attn_dma16(const void* src, unsigned lds_base) {
 }
 template <int N> __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int HD, int QT, int NW>
+template <typename T, int HD, int QT, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_desc p) {
     typedef typename Vec<T>::v8 V8;
     constexpr int NC = HD / 16;                        // 16-deep contraction chunks of K Q^T
@@ -354,12 +354,15 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
     constexpr int CPR = RB / 16, RPB = 256 / RB;       // 16-byte slots per K row, K rows per 256 bytes
     constexpr int KB = 64;                             // keys per stage (one 128-byte line of every V^T row)
     constexpr int KIMG = KB * RB, VIMG = RT * 32 * 128, STAGE = KIMG + VIMG;
-    constexpr int NKP = KIMG / 1024, NVP = HD * 128 / 1024, NP = NKP + NVP;   // DMA pieces per stage (real V^T rows only)
-    constexpr int PPW = (NP + NW - 1) / NW;            // ... per wave (the same for every wave: dummies fill up)
+    constexpr int NKP = KIMG / 1024, NVP = HD * 128 / 1024, NP = NKP + NVP;   // DMA pieces per 64-key block (real V^T rows only)
+    // A ring step (one wait + one barrier + one refill) moves U 64-key blocks: the per-step costs - every wave's DMA issue (dummies
+    // included), the counted wait, the barrier - are paid once per 2 U score tiles of a wave instead of once per 2
+    constexpr int SSTAGE = U * STAGE;                  // bytes of a ring step
+    constexpr int PPW = (U * NP + NW - 1) / NW;        // pieces per wave and step (the same for every wave: dummies fill up)
     constexpr int NST = 3;
     constexpr int QW = 32 * QT, QWG = QW * NW;
     constexpr float RESCALE_THR = 8.f;
-    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 1024];     // ring + landing area of dummy pieces
+    __shared__ __attribute__((aligned(16))) char smem[NST * SSTAGE + 1024];    // ring + landing area of dummy pieces
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -382,7 +385,8 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
     const T* __restrict__ Vb = (const T*)p.VT + bh * HD * (long)p.Tp + tok0;
     const int q0 = qblk * QWG + wave * QW;
     const bool active = q0 < nkeys;                    // wave-uniform; idle waves still feed the ring and hit the barriers
-    const int nblk = (nkeys + KB - 1) / KB;            // a ragged last stage is masked in the softmax (keys >= nkeys)
+    const int nblk = (nkeys + KB - 1) / KB;            // 64-key blocks; a ragged last one is masked in the softmax (keys >= nkeys)
+    const int nstep = (nblk + U - 1) / U;              // ring steps (blocks past the sequence: dummy pieces, no compute)
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = m][16c + 8h .. + 7]
     V8 qf[QT][NC];
@@ -399,34 +403,37 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
     // whose run starts at or past nkeys read the zero page. A run that straddles nkeys (nkeys % 8 == 4) is fetched whole -
     // 8 bytes past the sequence, inside the V^T tensor except for its very last row: the caller guarantees that slack
     // (lwdetr_attn_desc.vt_slack), otherwise such shapes stay on attn_kernel.
-    const T* src0[PPW]; const T* srct[PPW]; int sstep[PPW]; unsigned dst0[PPW]; bool real[PPW];
+    const T* src0[PPW]; const T* srct[PPW]; int sstep[PPW]; unsigned dst0[PPW]; bool real[PPW]; int sub[PPW];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
-    const unsigned dummy_dst = lds0 + NST * STAGE;
+    const unsigned dummy_dst = lds0 + NST * SSTAGE;
     const int kt0 = (nblk - 1) * KB;                    // first key of the last block
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int i = wave + j * NW;
-        if (i < NKP) {
+        const int ii = wave + j * NW;
+        const int i = ii % NP;                          // piece of its 64-key block
+        sub[j] = ii / NP;                               // block of the step
+        if (ii >= U * NP) {
+            src0[j] = (const T*)g_attn_zero16; srct[j] = src0[j]; sstep[j] = 0; dst0[j] = 0; real[j] = false;
+        } else if (i < NKP) {
             const int off = i * 1024 + lane * 16;                       // byte offset inside the K image
             const int key = off / RB, slot = (off % RB) / 16;
             const int chunk = slot ^ ((key / RPB) & (CPR - 1));
-            src0[j] = Kb + key * HD + chunk * 8; sstep[j] = KB * HD; dst0[j] = i * 1024; real[j] = true;
+            src0[j] = Kb + key * HD + chunk * 8; sstep[j] = KB * HD; dst0[j] = sub[j] * STAGE + i * 1024; real[j] = true;
             const int kc = kt0 + key < nkeys ? kt0 + key : nkeys - 1;
             srct[j] = Kb + (long)kc * HD + chunk * 8;
-        } else if (i < NP) {
+        } else {
             const int v = i - NKP;
             const int row = 8 * v + (lane >> 3), slot = lane & 7;
             const int chunk = slot ^ ((row >> 1) & 7);
-            src0[j] = Vb + (long)row * p.Tp + chunk * 8; sstep[j] = KB; dst0[j] = KIMG + v * 1024; real[j] = true;
+            src0[j] = Vb + (long)row * p.Tp + chunk * 8; sstep[j] = KB; dst0[j] = sub[j] * STAGE + KIMG + v * 1024; real[j] = true;
             srct[j] = kt0 + chunk * 8 < nkeys ? src0[j] + kt0 : (const T*)g_attn_zero16;
-        } else {
-            src0[j] = (const T*)g_attn_zero16; srct[j] = src0[j]; sstep[j] = 0; dst0[j] = 0; real[j] = false;
         }
     }
-    auto issue = [&](int blk, int slot_) {             // always PPW pieces per wave: the wait counts are constants
-        const unsigned sb = lds0 + slot_ * STAGE;
+    auto issue = [&](int step, int slot_) {            // always PPW pieces per wave: the wait counts are constants
+        const unsigned sb = lds0 + slot_ * SSTAGE;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
+            const int blk = step * U + sub[j];
             const bool live = real[j] && blk < nblk;    // wave-uniform
             const T* src = !live ? (const T*)g_attn_zero16 : (blk == nblk - 1 ? srct[j] : src0[j] + (long)blk * sstep[j]);
             attn_dma16(src, __builtin_amdgcn_readfirstlane(live ? sb + dst0[j] : dummy_dst));
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
         V8 one8, zero8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { one8[e] = from_f32<T>(1.f); zero8[e] = from_f32<T>(0.f); }
-        for (int i = threadIdx.x; i < NST * 16 * 8; i += NW * 64) {       // 16 rows x 8 slots per stage
+        for (int i = threadIdx.x; i < NST * U * 16 * 8; i += NW * 64) {   // 16 rows x 8 slots per 64-key image
             const int st = i / 128, r = (i % 128) / 8, sl = i % 8;
             *(V8*)(smem + st * STAGE + KIMG + (16 + r) * 128 + sl * 16) = r == 0 ? one8 : zero8;
         }
@@ -481,19 +488,24 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
         for (int c = 0; c < NC; ++c) asm volatile("" :: "v"(qf[t][c]));
 
     int slot = 0;
-    for (int kb = 0; kb < nblk; ++kb) {
+    for (int ks = 0; ks < nstep; ++ks) {
         // every K / V^T fragment read of stage kb - 1 has returned before this wave lets the others refill that buffer: hipcc does
         // not see the DMA and may sink the last MFMAs of a stage (and the lgkmcnt wait of their operands) below the barrier
         // (the 3x3 convolution kernel was caught by exactly this beside another stream's LDS-heavy kernels, gemm.hip)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        attn_wait_vmcnt<(NST - 2) * PPW>();            // stage kb has landed (this wave's pieces) ...
-        __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody has also left stage kb - 1
+        attn_wait_vmcnt<(NST - 2) * PPW>();            // step ks has landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                  // ... and everybody's; everybody has also left step ks - 1
         {
             int ns = slot + NST - 1; ns = ns >= NST ? ns - NST : ns;
-            issue(kb + NST - 1, ns);                   // refill the buffer stage kb - 1 used
+            issue(ks + NST - 1, ns);                   // refill the buffer step ks - 1 used
         }
-        const char* sK = smem + slot * STAGE;
+        const char* sS = smem + slot * SSTAGE;
         slot = slot + 1 == NST ? 0 : slot + 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+        const int kb = ks * U + u;
+        if (kb >= nblk) break;                         // blocks past the sequence (wave-uniform)
+        const char* sK = sS + u * STAGE;
         if (active) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -575,6 +587,7 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
         } else {
             res0 += 64; res0 %= p.sub_stride;
         }
+        }
     }
     attn_wait_vmcnt<0>();                              // the dummy tail pieces
     if (!active) return;
@@ -620,16 +633,19 @@ __global__ __launch_bounds__(NW * 64) void attn_lds_kernel(const lwdetr_attn_des
     }
 }
 
-template <typename T, int HD, int QT, int NW>
+template <typename T, int HD, int QT, int NW, int U = 1>
 int launch_lds(const lwdetr_attn_desc& p, hipStream_t st) {
+    if constexpr (3 * U * (64 * HD * 2 + (HD > 32 ? HD / 32 : 1) * 32 * 128) + 1024 > 65536) return LWDETR_ERR_UNSUPPORTED;   // two workgroups per CU
+    else {
     const int wgs_per_seq = (p.keys_per_seq + 32 * QT * NW - 1) / (32 * QT * NW);
     const long nwg = (long)wgs_per_seq * p.heads * p.B * p.seqs_per_img;
     const double nseq = (double)p.B * p.seqs_per_img;
     const double flops = 4.0 * nseq * p.heads * (double)p.keys_per_seq * p.keys_per_seq * HD;
     const double bytes = 4.0 * nseq * p.heads * p.keys_per_seq * HD * sizeof(T);
     ProfScope ps(p.kind == 0 ? KID_ATTN_WINDOW : (p.kind == 1 ? KID_ATTN_GLOBAL : KID_ATTN_DECODER), flops, bytes, st);
-    hipLaunchKernelGGL((attn_lds_kernel<T, HD, QT, NW>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((attn_lds_kernel<T, HD, QT, NW, U>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
     return lwdetr_check_launch();
+    }
 }
 
 // The LDS-ring kernel serves long, 64-aligned sequences of the 16-bit types; everything else (windows, the decoder's 300
@@ -641,18 +657,32 @@ int launch_lds(const lwdetr_attn_desc& p, hipStream_t st) {
 // hd <= 32 is bound by the exponentials (v_exp_f32 issues at 8.5 cycles per wave and does NOT overlap other VALU work on
 // this chip, tools/ubench/overlap.hip): 32 queries per wave keep the register count at 84-92 (5 waves per SIMD), which is
 // what hides the LDS / barrier latencies there; hd = 64 is matrix-bound and prefers the K / V^T reuse of 64 queries per wave.
+int g_attn_lds_cfg = 0;         // lwdetr_attention_tuning_cfg(): overrides the environment / default (tests)
 template <typename T, int HD>
 int launch_lds_cfg(const lwdetr_attn_desc& p, hipStream_t st) {
     static const char* cfg = getenv("LWDETR_ATTN_LDS_CFG");
-    int c = cfg ? atoi(cfg) : 0;
-    if (!c) c = p.keys_per_seq <= 128 ? 104 : (HD >= 64 && p.keys_per_seq >= 512 ? 208 : 108);   // a 100-key window = 4 waves of 32 queries
+    int c = g_attn_lds_cfg ? g_attn_lds_cfg : (cfg ? atoi(cfg) : 0);
+    // a 100-key window = 4 waves of 32 queries. hd 16 (round 4): 128-query workgroups (13 per 1600-query image and head, the last
+    // half idle; 4-5 resident per CU) beat 256-query ones (7, the last three quarters idle; 2 per CU): 161 vs 180 us on the bench
+    // shape, +1.6 % on config 2 (profiles/r4f_attn_global_workgroup_sizes.txt); hd 32 is indifferent, hd 64 wants the K / V^T reuse
+    if (!c) c = p.keys_per_seq <= 128 || HD == 16 ? 104 : (HD >= 64 && p.keys_per_seq >= 512 ? 208 : 108);
     switch (c) {
+        case 102: return launch_lds<T, HD, 1, 2>(p, st);
+        case 103: return launch_lds<T, HD, 1, 3>(p, st);
         case 104: return launch_lds<T, HD, 1, 4>(p, st);
+        case 105: return launch_lds<T, HD, 1, 5>(p, st);
+        case 106: return launch_lds<T, HD, 1, 6>(p, st);
         case 108: return launch_lds<T, HD, 1, 8>(p, st);
         case 110: return launch_lds<T, HD, 1, 10>(p, st);
         case 204: return launch_lds<T, HD, 2, 4>(p, st);
         case 205: return launch_lds<T, HD, 2, 5>(p, st);
         case 208: return launch_lds<T, HD, 2, 8>(p, st);
+        case 1104: return launch_lds<T, HD, 1, 4, 2>(p, st);
+        case 1105: return launch_lds<T, HD, 1, 5, 2>(p, st);
+        case 1108: return launch_lds<T, HD, 1, 8, 2>(p, st);       // 1000 (U - 1) + 100 QT + NW: 128 keys per ring step
+        case 1110: return launch_lds<T, HD, 1, 10, 2>(p, st);
+        case 3108: return launch_lds<T, HD, 1, 8, 4>(p, st);       // 256 keys per ring step
+        case 1208: return launch_lds<T, HD, 2, 8, 2>(p, st);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
 }
@@ -908,6 +938,7 @@ int dispatch_hd(const lwdetr_attn_desc& p, hipStream_t st) {
 }  // namespace
 
 extern "C" void lwdetr_attention_tuning(int lds_mode) { g_attn_lds_mode = lds_mode; }
+extern "C" void lwdetr_attention_tuning_cfg(int cfg) { g_attn_lds_cfg = cfg; }
 
 extern "C" int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* hip_stream) {
     if (!desc) return LWDETR_ERR_BAD_ARG;

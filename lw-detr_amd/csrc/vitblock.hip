@@ -136,7 +136,6 @@ __device__ __forceinline__ float gelu_s2(float x, float e) { return x * __builti
 template <typename T, int C, int NH, bool QKV>
 __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     typedef typename Vec<T>::v8 V8;
-    typedef typename Vec<T>::v4 V4;
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int KS = C / 16;                  // k-steps of a K = C contraction = fragments per piece
     constexpr int NTI = C / 32;                 // 32-row tiles along C

@@ -221,6 +221,21 @@ def _attn_ref(q, k, v, valid):
 @pytest.mark.parametrize("geom", ["window100", "global1600", "holes", "decoder300", "holes3648", "global704", "window100_slack",
                                   "window228_slack"])
 def test_attention(dtype, hd, geom):
+    _attention_case(dtype, hd, geom, 0)
+
+
+# every compiled shape of the LDS-ring kernel (the defaults are 104 at hd 16, 108 at hd 32, 208 at hd 64): waves per workgroup that do
+# / do not divide the sequence, 64 queries per wave, 128 keys per ring step (U = 2: the second block of the last step lies past the sequence)
+@pytest.mark.parametrize("cfg", [102, 103, 105, 106, 108, 110, 204, 205, 208, 1104, 1105, 1108, 1110, 1208])
+@pytest.mark.parametrize("hd,dtype,geom", [(16, torch.float16, "global1600"), (32, torch.bfloat16, "holes3648"), (16, torch.bfloat16, "global704"),
+                                           (32, torch.float16, "window228_slack"), (64, torch.float16, "holes3648")])
+def test_attention_lds_ring_shapes(cfg, hd, dtype, geom):
+    if hd == 64 and cfg >= 1000:
+        pytest.skip("two 64-key blocks per ring step do not fit the LDS budget at hd 64")
+    _attention_case(dtype, hd, geom, cfg)
+
+
+def _attention_case(dtype, hd, geom, cfg):
     from lwdetr_amd import kernels as K
     heads, b = 3, 2
     if geom == "holes3648":        # the real 960x960 geometry (LDS-ring kernel for the 16-bit types): 225 tokens in 228 rows
@@ -257,12 +272,14 @@ def test_attention(dtype, hd, geom):
     # these test batches are small); the other geometries / f32 exercise attn_kernel
     use_lds = slack or geom in ("global1600", "holes3648", "global704")
     _native.lib().lwdetr_attention_tuning(3 if use_lds else -1)
+    _native.lib().lwdetr_attention_tuning_cfg(cfg)
     try:
         K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd,
                  seqs_per_img=spi, seq_tok_stride=twp if spi == 16 else tp, keys_per_seq=keys, sub_stride=twp,
                  sub_len=tw, kind=0, vt_slack=slack)()
     finally:
         _native.lib().lwdetr_attention_tuning(-1)
+        _native.lib().lwdetr_attention_tuning_cfg(0)
     o = out.reshape(b, tp, heads, hd).permute(0, 2, 1, 3).float()
     qn = qs.float() / math.log2(math.e)      # kernel works in the log2 domain
     valid = (torch.arange(tp, device=_dev()) % twp) < tw

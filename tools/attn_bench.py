@@ -26,7 +26,13 @@ VARIANTS = [("attn_kernel", {"LWDETR_ATTN_LDS": "0", "LWDETR_ATTN_WIN": "0", "LW
             ("attn_kernel, loads up front short", {"LWDETR_ATTN_LDS": "0", "LWDETR_ATTN_WIN": "0"}), ("one wave / window win", {"LWDETR_ATTN_WIN": "1"}),
             ("lds 1x8", {"LWDETR_ATTN_LDS_CFG": "108", "LWDETR_ATTN_WIN": "0"}),
             ("lds 1x10", {"LWDETR_ATTN_LDS_CFG": "110"}), ("lds 2x4", {"LWDETR_ATTN_LDS_CFG": "204"}),
-            ("lds 2x5", {"LWDETR_ATTN_LDS_CFG": "205"}), ("lds 2x8", {"LWDETR_ATTN_LDS_CFG": "208"})]
+            ("lds 2x5", {"LWDETR_ATTN_LDS_CFG": "205"}), ("lds 2x8", {"LWDETR_ATTN_LDS_CFG": "208"}),
+            # 128 / 256 keys per ring step (round 4): 1000 (U - 1) + 100 QT + NW
+            ("lds 1x8u2", {"LWDETR_ATTN_LDS_CFG": "1108"}), ("lds 1x10u2", {"LWDETR_ATTN_LDS_CFG": "1110"}),
+            ("lds 1x4", {"LWDETR_ATTN_LDS_CFG": "104", "LWDETR_ATTN_WIN": "0"}), ("lds 1x5", {"LWDETR_ATTN_LDS_CFG": "105"}),
+            ("lds 1x2", {"LWDETR_ATTN_LDS_CFG": "102"}), ("lds 1x3", {"LWDETR_ATTN_LDS_CFG": "103"}), ("lds 1x6", {"LWDETR_ATTN_LDS_CFG": "106"}),
+            ("lds 1x4u2", {"LWDETR_ATTN_LDS_CFG": "1104"}), ("lds 1x5u2", {"LWDETR_ATTN_LDS_CFG": "1105"}),
+            ("lds 1x8u4", {"LWDETR_ATTN_LDS_CFG": "3108"}), ("lds 2x8u2", {"LWDETR_ATTN_LDS_CFG": "1208"})]
 
 
 def child(shape):
@@ -48,6 +54,11 @@ def child(shape):
                   kind=0 if win else 1, vt_slack=True)
     for _ in range(3):
         op()
+    err = ""
+    if os.environ.get("ATTN_BENCH_CHECK") == "1" and not win and tw == twp:       # against torch in f32 (global attention, no pad rows)
+        ref = torch.softmax(q.float() @ k.float().transpose(-1, -2) * 0.6931471805599453, -1) @ vt.float().transpose(-1, -2)   # q carries hd^-0.5 log2(e): the kernel works in base 2
+        got = out.view(B, Tp, heads, hd).permute(0, 2, 1, 3).float()
+        err = f"  max|d| vs torch f32 {float((got - ref).abs().max()):.2e}"
     ts = []
     for _ in range(15):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -56,7 +67,7 @@ def child(shape):
     ts.sort()
     flops = 4.0 * B * heads * Tp * (twp if win else Tp) * hd
     med = ts[len(ts) // 2]
-    print(f"{med:9.1f} us (min {ts[0]:.1f})  {flops / med / 1e6:7.1f} TFLOP/s", flush=True)
+    print(f"{med:9.1f} us (min {ts[0]:.1f})  {flops / med / 1e6:7.1f} TFLOP/s{err}", flush=True)
 
 
 def main():
