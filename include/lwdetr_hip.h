@@ -260,6 +260,18 @@ long lwdetr_vit_qkv_vec_floats(int C);
 int lwdetr_vit_qkv(const void* x, long ldx, const void* wstream, const float* vec, long M, int C, float eps, void* q_out,
                    void* k_out, void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream);
 
+/* The ViT stem in one launch (round 4): x0 = patches Wpe^T + b + pos - the 16 x 16 / stride 16 patch embedding of the NCHW image plus
+ * the absolute position embedding (models/backbone/vit.py:353-358, the PatchEmbed Conv2d) - stored to x (M, ldx) as the residual
+ * stream, and norm1 + QKV of block 0 from the registers (vit.py:199, :123-130; outputs as lwdetr_vit_qkv). img: (B, 3, 16 Hp, 16 Wp) of
+ * the model dtype; rows of x are the window-major tokens of layout (Hp, Wp, Twp) (pad rows: zero pixels), M = B * 16 * Twp; pos:
+ * (16 Twp, ldpos) of the model dtype in the same token order. wstream / vec: lwdetr_amd.kernels.pack_vit_stem. Replaces the
+ * PATCH16 lwdetr_gemm + lwdetr_vit_qkv pair; same rounding points (x0 rounded once from f32). C in {192, 384}, 16-bit dtypes. */
+long lwdetr_vit_stem_stream_bytes(int C);
+long lwdetr_vit_stem_vec_floats(int C);
+int lwdetr_vit_stem(const void* img, int B, int img_h, int img_w, int Hp, int Wp, int Twp, const void* pos, long ldpos, void* x,
+                    long ldx, const void* wstream, const float* vec, long M, int C, float eps, void* q_out, void* k_out,
+                    void* vt_out, float qscale, int heads, int hd, int dtype, void* hip_stream);
+
 /* ---- fused glue of the two-stage selection / decoder set-up (reference models/transformer.py:236-276, :42-68, :352-355;
  * models/lwdetr.py:150-155, :168-170). idx (B,nq) int64 = two-stage top-k; props (B,S,4) f32 anchor proposals. ---- */
 int lwdetr_select_gather(const void* om, const void* enc_cls, long ldc, const float* props, const int64_t* idx,

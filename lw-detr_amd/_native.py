@@ -105,6 +105,11 @@ def lib():
         l.lwdetr_vit_block_vec_floats.argtypes = [i]
         l.lwdetr_vit_block_vec_floats.restype = C.c_long
         l.lwdetr_vit_qkv.argtypes = [vp, lg, vp, vp, lg, i, f, vp, vp, vp, f, i, i, i, i, vp]
+        l.lwdetr_vit_stem.argtypes = [vp, i, i, i, i, i, i, vp, lg, vp, lg, vp, vp, lg, i, f, vp, vp, vp, f, i, i, i, vp]
+        l.lwdetr_vit_stem_stream_bytes.argtypes = [i]
+        l.lwdetr_vit_stem_stream_bytes.restype = C.c_long
+        l.lwdetr_vit_stem_vec_floats.argtypes = [i]
+        l.lwdetr_vit_stem_vec_floats.restype = C.c_long
         l.lwdetr_vit_qkv_stream_bytes.argtypes = [i]
         l.lwdetr_vit_qkv_stream_bytes.restype = C.c_long
         l.lwdetr_vit_qkv_vec_floats.argtypes = [i]
@@ -134,7 +139,7 @@ def lib():
         l.lwdetr_prof_kernel_name.restype = C.c_char_p
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
         for fn in ("lwdetr_msda_forward", "lwdetr_msda_backward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
-                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_enc_chain", "lwdetr_row_chain", "lwdetr_mlp_fused", "lwdetr_vit_block", "lwdetr_vit_qkv", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
+                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_enc_chain", "lwdetr_row_chain", "lwdetr_mlp_fused", "lwdetr_vit_block", "lwdetr_vit_qkv", "lwdetr_vit_stem", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
                    "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_postprocess_packed", "lwdetr_finalize_outputs", "lwdetr_resize_normalize", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int
         _lib = l

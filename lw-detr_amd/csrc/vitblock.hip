@@ -896,6 +896,360 @@ int launch_vq(const VbParams& p, hipStream_t st) {
     return lwdetr_check_launch();
 }
 
+
+// ------------------------------------------------------------------------------------------- patch embedding + norm1 + QKV
+// The ViT stem as one launch (round 4): x0 = patches Wpe^T + b + pos (vit.py:353-358: Conv2d(3, C, 16, stride 16) on the NCHW image
+// + absolute position embedding), stored as the residual stream, then block 0's norm1 + QKV from the registers (vit.py:199,
+// :123-130) - the patch GEMM (58 us at BASELINE config 2: a 64 x 64 tiling re-gathers every pixel for three column tiles) and
+// lwdetr_vit_qkv (30 us) before. A wave owns 32 NH window-major tokens exactly as vitblock_kernel does; the contraction runs over
+// k = (channel, patch row, pixel) in 48 steps of 16 pixels = ONE 32-byte patch row per token, which a lane pair reads straight from
+// the image as the B operand (two steps of four rows ahead of the MFMAs that consume them: no LDS, every pixel read once). Wpe
+// streams through the same ring as every other weight of the ViT: piece i = fragments (k-step 2 i + kk, channel tile n), kk-major.
+// The accumulators start at pos + b; x0 is rounded to the storage type once (as the GEMM epilogue did), and the QKV phase is the
+// one of vitblock_kernel (weights in accumulator k-slot order).
+struct VsParams {
+    const void* img; unsigned img_bytes; int img_h, img_w;     // (B, 3, H, W) of T
+    int Hp, Wp, Twp;                                           // window-major token layout (common.h: tok_decode)
+    const void* pos; long ldpos;                               // (Tp, C) of T: position embedding in token order (zero pad rows)
+    VbParams v;                                                // x (out), wstream, vec, q / k / vt, M, eps_next, qscale, heads, hd_log2, Tp
+};
+
+template <typename T, int C, int NH>
+__global__ __launch_bounds__(256, 1) void vit_stem_kernel(const VsParams ps) {
+    typedef typename Vec<T>::v8 V8;
+    static_assert(sizeof(T) == 2, "16-bit types only");
+    const VbParams& p = ps.v;
+    constexpr int KS = C / 16, NTI = C / 32;
+    constexpr int PIECE_B = KS * 1024, DPW = KS / 4;
+    constexpr int NSLOT = C == 192 ? 8 : 5;
+    constexpr int VEC_B = (4 * C * 4 + 4095) / 4096 * 4096, VEC_DPW = VEC_B / 4096;
+    constexpr int NP_PE = 24, NP_QKV = 3 * NTI, NP = NP_PE + NP_QKV, Q0 = NP_PE;
+    constexpr int NSTEP = NP_PE / 2;            // ring steps of the patch phase: 2 pieces = 4 k-steps (patch rows) each
+    constexpr int NPX = NH * 4;                 // pixel loads per step
+    constexpr int PF = 2;                       // pixel loads run PF steps ahead (three register buffers)
+    constexpr int RD = NH == 2 ? 4 : 8;
+    static_assert(DPW % 3 == 0 && KS == 2 * NTI, "wait counts are kept in multiples of 3");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float* vec = (const float*)(smem + NSLOT * PIECE_B);
+    const float* bpe = vec; const float* bqs = vec + C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const unsigned lane16 = lane * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    const long U = p.M >> 3, nwv = (long)gridDim.x * 4, wg = (long)blockIdx.x * 4 + wave;
+    const long u0 = wg * U / nwv, u1 = (wg + 1) * U / nwv;
+    const long t0 = u0 * 8;
+    const int nvalid = (int)(u1 - u0) * 8;
+    const char* wsrc = (const char*)p.wstream;
+    auto dma1k = [&](const char* src_uniform, unsigned voff, unsigned lds_dst) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)src_uniform);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)src_uniform >> 32));
+        const char* sp = (const char*)(((uintptr_t)hi << 32) | lo);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(sp) : "memory");
+    };
+    auto dma_piece = [&](int piece) {
+        const unsigned slot = (unsigned)piece % NSLOT;
+        const char* src = wsrc + (size_t)piece * PIECE_B;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const unsigned kb = (unsigned)(wave * DPW + i) * 1024u;
+            dma1k(src, kb + lane16, lds0 + slot * PIECE_B + kb);
+        }
+    };
+    int issued = 0;
+    auto boundary = [&](int a, int b, int extra) {
+        __builtin_amdgcn_sched_barrier(0);
+        vb_wait_le((issued - b) * DPW + extra);
+        __builtin_amdgcn_s_barrier();
+        int lim = a + NSLOT; lim = lim < NP ? lim : NP;
+        while (issued < lim) { dma_piece(issued); ++issued; }
+    };
+    auto frag = [&](int piece, int f) -> V8 { return *(const V8*)(smem + ((unsigned)piece % NSLOT) * PIECE_B + f * 1024 + lane16); };
+    {
+        const char* vsrc = (const char*)p.vec;
+#pragma unroll
+        for (int i = 0; i < VEC_DPW; ++i) {
+            const unsigned kb = (unsigned)(wave * VEC_DPW + i) * 1024u;
+            dma1k(vsrc, kb + lane16, lds0 + NSLOT * PIECE_B + kb);
+        }
+        for (; issued < NSLOT; ++issued) dma_piece(issued);
+    }
+    // ---- this lane's tokens: byte offset of pixel (0, 8 h) of the patch in channel 0, row of the position table
+    const __amdgpu_buffer_rsrc_t r_img = __builtin_amdgcn_make_buffer_rsrc((void*)ps.img, 0, (int)ps.img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_pos = __builtin_amdgcn_make_buffer_rsrc((void*)ps.pos, 0, (int)(p.Tp * ps.ldpos * 2), 0x00020000);
+    T* x_w = (T*)p.x + t0 * p.ldx;
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)x_w, 0, (int)(nvalid * p.ldx * 2), 0x00020000);
+    unsigned pix0[NH], prow[NH];
+    {
+        TokLayout L; L.winmajor = 1; L.Hp = ps.Hp; L.Wp = ps.Wp; L.Twp = ps.Twp;
+#pragma unroll
+        for (int th = 0; th < NH; ++th) {
+            const long tok = t0 + 32 * th + j;
+            const TokPos tp = tok_decode(tok, L);
+            const bool ok = 32 * th + j < nvalid && tp.valid;
+            pix0[th] = ok ? (unsigned)((((long)tp.b * 3 * ps.img_h + tp.y * 16) * ps.img_w + tp.x * 16 + 8 * h) * 2) : 0x80000000u;
+            prow[th] = (unsigned)((tok % p.Tp) * ps.ldpos * 2);
+        }
+    }
+    const unsigned plane_b = (unsigned)ps.img_h * (unsigned)ps.img_w * 2u, row_b = (unsigned)ps.img_w * 2u;
+    V8 px[PF + 1][NH][4];                       // [buffer = step % 3][token half][patch row of the step]
+    auto load_px = [&](auto step_tag) {
+        constexpr int st = decltype(step_tag)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            constexpr int dummy = 0; (void)dummy;
+            const int t = 4 * st + kk, ch = t >> 4, py = t & 15;                 // compile-time after unrolling
+            const unsigned so = __builtin_amdgcn_readfirstlane(ch * plane_b + py * row_b);
+#pragma unroll
+            for (int th = 0; th < NH; ++th)
+                px[st % (PF + 1)][th][kk] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(r_img, pix0[th], so, 0));
+        }
+    };
+    // position rows (16-byte loads, channels 32 n + 16 jb + 8 h .. + 7 of the token), then the pixels of steps 0 and 1
+    f32x16 acc2[NTI][NH];
+    {
+        u32x4 pv[NH][NTI][2];
+#pragma unroll
+        for (int th = 0; th < NH; ++th)
+#pragma unroll
+            for (int n = 0; n < NTI; ++n)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+                    pv[th][n][jb] = __builtin_amdgcn_raw_buffer_load_b128(r_pos, prow[th] + (unsigned)((32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+        load_px(std::integral_constant<int, 0>{});
+        load_px(std::integral_constant<int, 1>{});
+        boundary(0, 2, NH * NTI * 2 + 2 * NPX);
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+            f32x16 na[NH];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int th = 0; th < NH; ++th) {
+                    const u32x4 own = vb_rows8(pv[th][n][jb][0], pv[th][n][jb][1], pv[th][n][jb][2], pv[th][n][jb][3]);
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int b = 2 * jb + bb, c0 = 32 * n + 8 * b + 4 * h;
+                        const f32x4 bbv = *(const f32x4*)(bpe + c0);
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            const unsigned ow_ = own[2 * bb + d];
+                            const typename Pk<T>::v2 v2 = __builtin_bit_cast(typename Pk<T>::v2, ow_);
+                            na[th][4 * b + 2 * d] = to_f32<T>(v2[0]) + bbv[2 * d];
+                            na[th][4 * b + 2 * d + 1] = to_f32<T>(v2[1]) + bbv[2 * d + 1];
+                        }
+                    }
+                }
+#pragma unroll
+            for (int th = 0; th < NH; ++th) {
+                asm volatile("" : "+a"(na[th]));
+                acc2[n][th] = na[th];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- patch phase: step s = pieces 2 s, 2 s + 1 = patch rows 4 s .. 4 s + 3, fragments (row, channel tile) in stream order.
+    // Vector-memory operations younger than a step's pieces besides later pieces (exact; the compiler's own waits for the pixel
+    // registers see only its loads and can only wait longer): the position loads and every pixel group issued since.
+    vb_static_for<NSTEP>([&](auto s_tag) {
+        constexpr int s = decltype(s_tag)::value;
+        if constexpr (s > 0) {
+            constexpr int npos = s < 4 ? NH * NTI * 2 : 0;
+            constexpr int hi = s + 1 < NSTEP - 1 ? s + 1 : NSTEP - 1;           // youngest pixel group issued before this boundary
+            constexpr int lo = s < 4 ? 0 : s - 1;                               // oldest one younger than piece 2 s + 1
+            boundary(2 * s, 2 * s + 2, npos + (hi - lo + 1) * NPX);
+        }
+        if constexpr (s + PF < NSTEP) load_px(std::integral_constant<int, s + PF>{});
+        V8 fr[RD];
+#pragma unroll
+        for (int i = 0; i < RD; ++i) fr[i] = frag(2 * s + i / KS, i % KS);
+#pragma unroll
+        for (int fi = 0; fi < 2 * KS; ++fi) {
+            const int kk = fi / NTI, n = fi % NTI;
+            const V8 a = fr[fi % RD];
+#pragma unroll
+            for (int th = 0; th < NH; ++th) acc2[n][th] = Mma32<T>::k16(a, px[s % (PF + 1)][th][kk], acc2[n][th]);
+            if (fi + RD < 2 * KS) fr[fi % RD] = frag(2 * s + (fi + RD) / KS, (fi + RD) % KS);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+    // ---- x0 rounded to the storage type and stored; its statistics; LN(x0) as the B operand of the QKV phase
+    V8 xf[NH][KS];
+#pragma unroll
+    for (int th = 0; th < NH; ++th) {
+        float sm = 0.f;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                unsigned pw[4];
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int b = 2 * jb + bb;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const unsigned w = pack2<T>(acc2[n][th][4 * b + 2 * d], acc2[n][th][4 * b + 2 * d + 1]);
+                        pw[2 * bb + d] = w;
+                        const typename Pk<T>::v2 v2 = __builtin_bit_cast(typename Pk<T>::v2, w);
+                        const float v0 = to_f32<T>(v2[0]), v1 = to_f32<T>(v2[1]);
+                        acc2[n][th][4 * b + 2 * d] = v0; acc2[n][th][4 * b + 2 * d + 1] = v1;
+                        sm += v0 + v1;
+                    }
+                }
+                const u32x4 ow = vb_rows8(pw[0], pw[1], pw[2], pw[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(ow, r_x, (unsigned)(((32 * th + j) * p.ldx + 32 * n + 16 * jb + 8 * h) * 2), 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sm += __shfl_xor(sm, 32);
+        const float mean = sm * (1.f / C);
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float dl = acc2[n][th][e] - mean; v += dl * dl; }
+        v += __shfl_xor(v, 32);
+        const float rstd = 1.f / sqrtf(v * (1.f / C) + p.eps_next), nmr = -mean * rstd;
+#pragma unroll
+        for (int n = 0; n < NTI; ++n)
+#pragma unroll
+            for (int be = 0; be < 2; ++be) {
+                u32x4 w;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int r = (2 * be + (d >> 1)) * 4 + (d & 1) * 2;
+                    w[d] = pack2<T>(fmaf(acc2[n][th][r], rstd, nmr), fmaf(acc2[n][th][r + 1], rstd, nmr));
+                }
+                xf[th][2 * n + be] = __builtin_bit_cast(V8, w);
+            }
+    }
+    auto bias16 = [&](const float* src) -> f32x16 {
+        f32x16 r;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 v = *(const f32x4*)(src + 8 * b + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[4 * b + e] = v[e];
+        }
+        return r;
+    };
+    // ---- norm1 + QKV of block 0: as the chained phase of vitblock_kernel
+    const __amdgpu_buffer_rsrc_t r_q = __builtin_amdgcn_make_buffer_rsrc(p.q, 0, (int)p.qkv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc(p.k, 0, (int)p.qkv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(p.vt, 0, (int)p.qkv_bytes, 0x00020000);
+    const int hd = 1 << p.hd_log2;
+    unsigned row_qk[NH];
+#pragma unroll
+    for (int th = 0; th < NH; ++th) {
+        const unsigned tok = (unsigned)t0 + 32 * th + j;
+        const unsigned img = tok / (unsigned)p.Tp, wi = tok - img * (unsigned)p.Tp;
+        row_qk[th] = 32 * th + j < nvalid ? (unsigned)(((long)img * p.heads * p.Tp + wi) << p.hd_log2) : 0x7fffffffu;
+    }
+    constexpr int XST = NH * NTI * 2, SPS = 2 * NH * 2, LAG = (NSLOT - 2) / 2;
+    unsigned row_v8[NH][2];
+#pragma unroll
+    for (int th = 0; th < NH; ++th)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int tl = 32 * th + 16 * jb + 8 * h;
+            const unsigned tk = (unsigned)t0 + tl;
+            const unsigned im = tk / (unsigned)p.Tp, wv = tk - im * (unsigned)p.Tp;
+            row_v8[th][jb] = tl < nvalid ? (unsigned)((long)im * p.heads * hd * p.Tp + wv) : 0x7fffffffu;
+        }
+#pragma unroll 1
+    for (int s = 0; s < NP_QKV / 2; ++s) {
+        boundary(Q0 + 2 * s, Q0 + 2 * s + 2, s < LAG ? XST + SPS * s : SPS * LAG);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int pi = 2 * s + pp, piece = Q0 + pi;
+            const int sg = pi / NTI, nl0 = (pi - sg * NTI) * 32;
+            f32x16 acc[NH];
+            if (sg < 2) {
+                const f32x16 bias = bias16(bqs + sg * C + nl0);
+                V8 fr[RD];
+#pragma unroll
+                for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    const V8 a = fr[t % RD];
+#pragma unroll
+                    for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(a, xf[th][t], t == 0 ? bias : acc[th]);
+                    if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (sg == 0) {
+#pragma unroll
+                    for (int th = 0; th < NH; ++th)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[th][e] *= p.qscale;
+                }
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const int f = nl0 + 16 * jb + 8 * h, hh = f >> p.hd_log2, dd = f & (hd - 1);
+                    const unsigned col = (unsigned)(((long)hh * p.Tp << p.hd_log2) + dd);
+#pragma unroll
+                    for (int th = 0; th < NH; ++th) {
+                        const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
+                                                  pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
+                        const unsigned off = row_qk[th] == 0x7fffffffu ? 0x80000000u : (row_qk[th] + col) * 2u;
+                        if (sg == 0) __builtin_amdgcn_raw_buffer_store_b128(ow, r_q, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(ow, r_k, off, 0, 0);
+                    }
+                }
+            } else {
+                const float bv = bqs[2 * C + nl0 + j];
+                f32x16 binit;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) binit[e] = bv;
+                V8 fr[RD];
+#pragma unroll
+                for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    const V8 a = fr[t % RD];
+#pragma unroll
+                    for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(xf[th][t], a, t == 0 ? binit : acc[th]);
+                    if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int f = nl0 + j, hh = f >> p.hd_log2, dd = f & (hd - 1);
+                const unsigned rowb = (unsigned)(((long)hh * hd + dd) * p.Tp);
+#pragma unroll
+                for (int th = 0; th < NH; ++th)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+                        const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
+                                                  pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
+                        const unsigned off = row_v8[th][jb] == 0x7fffffffu ? 0x80000000u : (row_v8[th][jb] + rowb) * 2u;
+                        __builtin_amdgcn_raw_buffer_store_b128(ow, r_v, off, 0, 0);
+                    }
+            }
+        }
+    }
+}
+
+template <typename T, int C, int NH>
+int launch_vs(const VsParams& p, hipStream_t st) {
+    constexpr int KS = C / 16, PIECE_B = KS * 1024, NSLOT = C == 192 ? 8 : 5;
+    constexpr int VEC_B = (4 * C * 4 + 4095) / 4096 * 4096;
+    constexpr size_t lds = (size_t)NSLOT * PIECE_B + VEC_B;
+    static bool attr_done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)vit_stem_kernel<T, C, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return LWDETR_ERR_LAUNCH;
+        attr_done[dev] = true;
+    }
+    const long M = p.v.M, per_wg = 4L * 32 * NH;
+    long grid = (M + per_wg - 1) / per_wg;
+    while (((M / 8 + grid * 4 - 1) / (grid * 4)) * 8 > 32 * NH) ++grid;
+    ProfScope ps(KID_VITBLOCK, (2.0 * 768 + 6.0 * C) * M * C, (double)M * 768 * sizeof(T) + (double)M * C * sizeof(T) * 5, st);
+    hipLaunchKernelGGL((vit_stem_kernel<T, C, NH>), dim3((unsigned)grid), dim3(256), lds, st, p);
+    return lwdetr_check_launch();
+}
+
 struct VbLaunchState { bool attr_done; int ncu; };
 
 template <typename T, int C, int NH, bool QKV>
@@ -998,5 +1352,35 @@ extern "C" int lwdetr_vit_qkv(const void* x, long ldx, const void* wstream, cons
     hipStream_t st = (hipStream_t)hip_stream;
     if (C == 192) return dtype == DT_F16 ? launch_vq<f16, 192, 2>(p, st) : dtype == DT_BF16 ? launch_vq<bf16, 192, 2>(p, st) : LWDETR_ERR_UNSUPPORTED;
     if (C == 384) return dtype == DT_F16 ? launch_vq<f16, 384, 1>(p, st) : dtype == DT_BF16 ? launch_vq<bf16, 384, 1>(p, st) : LWDETR_ERR_UNSUPPORTED;
+    return LWDETR_ERR_UNSUPPORTED;
+}
+
+extern "C" long lwdetr_vit_stem_stream_bytes(int C) { return (C == 192 || C == 384) ? (24L + 3L * (C / 32)) * (C / 16) * 1024L : -LWDETR_ERR_UNSUPPORTED; }
+extern "C" long lwdetr_vit_stem_vec_floats(int C) { return ((4L * C * 4 + 4095) / 4096 * 4096) / 4; }
+
+extern "C" int lwdetr_vit_stem(const void* img, int B, int img_h, int img_w, int Hp, int Wp, int Twp, const void* pos, long ldpos, void* x,
+                               long ldx, const void* wstream, const float* vec, long M, int C, float eps, void* q_out, void* k_out,
+                               void* vt_out, float qscale, int heads, int hd, int dtype, void* hip_stream) {
+    if (!img || !pos || !x || !wstream || !vec || !q_out || !k_out || !vt_out || M < 0 || B <= 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    const int Tp = 16 * Twp;
+    if (img_h != 16 * Hp || img_w != 16 * Wp || Hp % 4 != 0 || Wp % 4 != 0 || Twp < (Hp / 4) * (Wp / 4) || M != (long)B * Tp) return LWDETR_ERR_BAD_ARG;
+    if (ldx % 8 != 0 || ldpos % 8 != 0 ||
+        ((uintptr_t)img | (uintptr_t)pos | (uintptr_t)x | (uintptr_t)wstream | (uintptr_t)vec | (uintptr_t)q_out | (uintptr_t)k_out | (uintptr_t)vt_out) % 16 != 0)
+        return LWDETR_ERR_BAD_ARG;
+    if (heads <= 0 || hd < 8 || (hd & (hd - 1)) != 0 || heads * hd != C || Tp % 8 != 0) return LWDETR_ERR_UNSUPPORTED;
+    if ((double)M * C * 2.0 >= 2147483000.0 || (double)ldx * 64 * 2 >= 2147483000.0 || (double)B * 3 * img_h * img_w * 2.0 >= 2147483000.0 ||
+        (double)Tp * ldpos * 2.0 >= 2147483000.0)
+        return LWDETR_ERR_UNSUPPORTED;
+    VsParams p = {};
+    p.img = img; p.img_bytes = (unsigned)((unsigned long)B * 3ul * img_h * img_w * 2ul); p.img_h = img_h; p.img_w = img_w;
+    p.Hp = Hp; p.Wp = Wp; p.Twp = Twp; p.pos = pos; p.ldpos = ldpos;
+    p.v.x = x; p.v.ldx = ldx; p.v.wstream = wstream; p.v.vec = vec; p.v.M = M; p.v.eps_next = eps; p.v.qscale = qscale;
+    int l2 = 0; while ((1 << l2) < hd) ++l2;
+    p.v.q = q_out; p.v.k = k_out; p.v.vt = vt_out; p.v.heads = heads; p.v.hd_log2 = l2; p.v.Tp = Tp;
+    p.v.qkv_bytes = (unsigned)((unsigned long)M * C * 2ul);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (C == 192) return dtype == DT_F16 ? launch_vs<f16, 192, 2>(p, st) : dtype == DT_BF16 ? launch_vs<bf16, 192, 2>(p, st) : LWDETR_ERR_UNSUPPORTED;
+    if (C == 384) return dtype == DT_F16 ? launch_vs<f16, 384, 1>(p, st) : dtype == DT_BF16 ? launch_vs<bf16, 384, 1>(p, st) : LWDETR_ERR_UNSUPPORTED;
     return LWDETR_ERR_UNSUPPORTED;
 }

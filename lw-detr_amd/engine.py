@@ -203,18 +203,33 @@ class ForwardPlan:
         self.taps_cat = z(rows, ntap * C)
         pos = pw.custom(f"pos.{self.Hp}x{self.Wp}", lambda: abs_pos_winmajor(pw.sd[pre + ".pos_embed"].detach().cpu(),
                                                                            self.Hp, self.Wp, self.Twp))
-        wpe = pw.w(pre + ".patch_embed.proj.weight", lambda t: t.reshape(t.shape[0], -1))
-        dummy_img = z(1, 8)
-        ops.append(GemmOp(dummy_img, wpe, rows, C, 768, [
-            seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp)],
-            a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
-        self.patch_op = ops[-1]
         qscale = K.attention_scale(hd)
         fused = K.mlp_fused_supported(C, self.T, rows)
+        blk0_fused = fused and K.vit_block_supported(C, self.T, hd, rows) and rows % Tp == 0 and Tp % 8 == 0
+        # round 4: patch embedding + position embedding + block 0's norm1 / QKV as ONE launch at the batch sizes of the block kernel
+        self.stem_op = self.patch_op = None
+        if (blk0_fused and os.environ.get("LWDETR_VIT_STEM", "1") != "0" and self.H == 16 * self.Hp and self.W == 16 * self.Wp
+                and self.Hp % 4 == 0 and self.Wp % 4 == 0 and Tp == 16 * self.Twp and pos.dtype == self.T):
+            b0 = pre + ".blocks.0"
+            ss, sv = pw.custom_multi(pre + ".vitstem.packed", lambda: K.pack_vit_stem(
+                pw.sd[pre + ".patch_embed.proj.weight"], pw.sd[pre + ".patch_embed.proj.bias"], pw.sd[b0 + ".attn.qkv.weight"],
+                pw.sd[b0 + ".attn.q_bias"], pw.sd[b0 + ".attn.v_bias"], pw.sd[b0 + ".norm1.weight"], pw.sd[b0 + ".norm1.bias"], self.T))
+            self.stem_op = K.VitStemOp(None, pos, self.x, ss, sv, B, self.Hp, self.Wp, self.Twp, C, 1e-6, q=q, k=k, vt=vt, qscale=qscale,
+                                       heads=heads, hd=hd)
+            ops.append(self.stem_op)
+        else:
+            wpe = pw.w(pre + ".patch_embed.proj.weight", lambda t: t.reshape(t.shape[0], -1))
+            dummy_img = z(1, 8)
+            ops.append(GemmOp(dummy_img, wpe, rows, C, 768, [
+                seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp)],
+                a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
+            self.patch_op = ops[-1]
         for i in range(self.depth):
             blk = f"{pre}.blocks.{i}"
             window = i in self.cfg.window_block_indexes
-            if i == 0 and fused and K.vit_block_supported(C, self.T, hd, rows) and rows % Tp == 0 and Tp % 8 == 0 and os.environ.get("LWDETR_VIT_QKV", "1") != "0":
+            if i == 0 and self.stem_op is not None:
+                pass                                     # q / k / v^T of block 0 come out of the stem launch
+            elif i == 0 and blk0_fused and os.environ.get("LWDETR_VIT_QKV", "1") != "0":
                 # block 0: norm1 + QKV in one launch (the QKV phase of the block kernel on its own; round 4)
                 sq, vq = pw.custom_multi(blk + ".vitqkv.packed", lambda blk=blk: K.pack_vit_qkv(
                     pw.sd[blk + ".attn.qkv.weight"], pw.sd[blk + ".attn.q_bias"], pw.sd[blk + ".attn.v_bias"],
@@ -721,7 +736,10 @@ class ForwardPlan:
                 self.images = self._z(B, 3, self.H, self.W)
             self.images.copy_(images)
             self._img_ref = self.images
-        self.patch_op.desc.A = self._img_ref.data_ptr()
+        if self.stem_op is not None:
+            self.stem_op.set_image(self._img_ref.data_ptr())
+        else:
+            self.patch_op.desc.A = self._img_ref.data_ptr()
         self._set_padding_state(mask)
         for op in self.ops_backbone:
             op(stream)

@@ -385,6 +385,56 @@ class VitQkvOp:
             _nat.check(rc, "vit_qkv")
 
 
+def pack_vit_stem(wpe, bpe, wqkv, q_bias, v_bias, ln_w, ln_b, dtype):
+    """Host-side packing for lwdetr_vit_stem (patch embedding + norm1 + QKV of block 0): stream = 24 patch pieces - piece i holds the
+    fragments (k-step 2 i + kk, channel tile n), kk-major, of Wpe (C, 768) with k = (channel, patch row, pixel) as the Conv2d weight
+    lies in memory - then the 3 C / 32 QKV pieces in accumulator k-slot order (as pack_vit_block's chained QKV, LayerNorm affine
+    folded); vec = patch bias | [q_bias, 0, v_bias] + W beta, zero-padded to a multiple of 4 KB."""
+    f = lambda t: t.detach().float().cpu()
+    wpe, bpe, wqkv, q_bias, v_bias, ln_w, ln_b = map(f, (wpe, bpe, wqkv, q_bias, v_bias, ln_w, ln_b))
+    c = wpe.shape[0]
+    wpe = wpe.reshape(c, -1)
+    assert c in (192, 384) and wpe.shape[1] == 768 and wqkv.shape == (3 * c, c)
+    nti = c // 32
+    pieces = []
+    for i in range(24):
+        for kk in range(2):
+            t = 2 * i + kk
+            pieces += [_vb_frags(wpe[32 * n:32 * n + 32, 16 * t:16 * t + 16]) for n in range(nti)]
+    perm = vb_kslot_channels(c)
+    bq = torch.cat([q_bias, torch.zeros_like(q_bias), v_bias]) + wqkv @ ln_b
+    wq = (wqkv * ln_w[None, :])[:, perm]
+    pieces += [_vb_frags(wq[32 * i:32 * i + 32]) for i in range(3 * nti)]
+    stream = torch.cat([p_.reshape(-1) for p_ in pieces]).to(dtype).contiguous()
+    vec = torch.cat([bpe, bq])
+    nvec = (4 * c * 4 + 4095) // 4096 * 4096 // 4
+    return stream, torch.cat([vec, torch.zeros(nvec - vec.numel())]).contiguous()
+
+
+class VitStemOp:
+    """x0 = patches Wpe^T + b + pos (stored), q, k, v^T = heads(LN(x0) Wqkv^T + b): the ViT stem in one launch (lwdetr_vit_stem).
+    ``img`` (B, 3, 16 Hp, 16 Wp) of the model dtype - ``set_image`` rebinds the pointer per call; ``pos`` (16 Twp, C) window-major."""
+
+    def __init__(self, img, pos, x, stream, vec, B, Hp, Wp, Twp, C_, eps, *, q, k, vt, qscale, heads, hd, ldx=None):
+        assert stream.dtype == x.dtype == pos.dtype and vec.dtype == torch.float32 and pos.is_contiguous() and pos.shape == (16 * Twp, C_)
+        lib = _nat.lib()
+        assert stream.numel() * 2 == lib.lwdetr_vit_stem_stream_bytes(C_) and vec.numel() == lib.lwdetr_vit_stem_vec_floats(C_)
+        self._img = _ptr(img) if img is not None else None
+        self.args = [None, B, 16 * Hp, 16 * Wp, Hp, Wp, Twp, _ptr(pos), C_, _ptr(x), ldx if ldx is not None else C_, _ptr(stream), _ptr(vec),
+                     B * 16 * Twp, C_, float(eps), _ptr(q), _ptr(k), _ptr(vt), float(qscale), heads, hd, _nat.dtype_code(x.dtype)]
+        self._keep = (img, pos, x, stream, vec, q, k, vt)
+        self._fn = lib.lwdetr_vit_stem
+
+    def set_image(self, ptr):
+        self._img = ptr
+
+    def __call__(self, stream=None):
+        self.args[0] = self._img
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "vit_stem")
+
+
 class VitBlockOp:
     """x <- block tail (attention projection + MLP, + norm1 / QKV of the next block) in one launch (lwdetr_vit_block)."""
 

@@ -186,3 +186,55 @@ def test_vit_qkv_matches_torch(dtype, c, heads, m, tp):
         assert torch.isfinite(got).all(), name
         err = (got - want).abs().max().item() / want.abs().max().item()
         assert err < tol, (name, err)
+
+
+@pytest.mark.parametrize("dtype,c,heads,b,hp,twp", [(torch.float16, 192, 12, 8, 40, 100), (torch.bfloat16, 192, 12, 3, 40, 100), (torch.float16, 384, 12, 4, 40, 100),
+                                                    (torch.bfloat16, 384, 12, 2, 60, 228), (torch.float16, 192, 12, 1, 44, 121)])
+def test_vit_stem_matches_torch(dtype, c, heads, b, hp, twp):
+    """lwdetr_vit_stem (patch embedding + position embedding + norm1 + QKV of block 0, one launch) vs Conv2d + add + LayerNorm + Linear in
+    fp32 on the same 16-bit operands (vit.py:353-358, :199, :123-130); 960 x 960 geometry: 225-token windows in 228 rows (zero pad rows)."""
+    g = torch.Generator().manual_seed(c + b + hp)
+    r = lambda *s: torch.randn(*s, generator=g)
+    hd, tp, hw = c // heads, 16 * twp, hp // 4
+    img = r(b, 3, 16 * hp, 16 * hp).to(dtype)
+    wpe, bpe = (r(c, 3, 16, 16) / 768 ** 0.5), r(c) * 0.1
+    wqkv, qb, vb = r(3 * c, c) / c ** 0.5, r(c) * 0.1, r(c) * 0.1
+    lw, lb = r(c) * 0.2 + 1, r(c) * 0.1
+    pos = torch.zeros(16, twp, c)
+    pos[:, :hw * hw] = r(16, hw * hw, c) * 0.5
+    pos = pos.reshape(tp, c).to(dtype)
+    stream, vec = K.pack_vit_stem(wpe, bpe, wqkv, qb, vb, lw, lb, dtype)
+    m = b * tp
+    x = torch.full((m, c), float("nan"), dtype=dtype, device=DEV)
+    q = torch.full((b, heads, tp, hd), float("nan"), dtype=dtype, device=DEV)
+    k = torch.full_like(q, float("nan"))
+    vt = torch.full((b, heads, hd, tp), float("nan"), dtype=dtype, device=DEV)
+    op = K.VitStemOp(img.to(DEV), pos.to(DEV), x, stream.to(DEV), vec.to(DEV), b, hp, hp, twp, c, 1e-6, q=q, k=k, vt=vt, qscale=0.37, heads=heads, hd=hd)
+    op()
+    torch.cuda.synchronize()
+    wd = wpe.to(dtype).float()
+    y = torch.nn.functional.conv2d(img.float(), wd, bpe, stride=16).permute(0, 2, 3, 1)                  # (b, hp, hp, c) raster
+    y = y.reshape(b, 4, hw, 4, hw, c).permute(0, 1, 3, 2, 4, 5).reshape(b, 16, hw * hw, c)                 # window-major
+    x0 = torch.zeros(b, 16, twp, c)
+    x0[:, :, :hw * hw] = y
+    x0[:, :, hw * hw:] = bpe                                                                               # pad rows: zero pixels
+    x0 = (x0.reshape(b, tp, c) + pos.float()[None]).to(dtype)
+    valid = (torch.arange(tp) % twp) < hw * hw
+    gx = x.float().cpu().reshape(b, tp, c)
+    assert torch.isfinite(gx).all()
+    tolx = {torch.float16: 3e-3, torch.bfloat16: 2.5e-2}[dtype]
+    errx = (gx - x0.float())[:, valid].abs().max().item() / x0.float().abs().max().item()
+    assert errx < tolx, ("x0", errx)
+    xn = torch.nn.functional.layer_norm(gx, (c,), lw, lb, 1e-6)                                           # from the kernel's own rounded x0
+    ref = xn @ (wqkv * 1.0).t() + torch.cat([qb, torch.zeros(c), vb])
+    rq = (ref[..., :c] * 0.37).view(b, tp, heads, hd).permute(0, 2, 1, 3)
+    rk = ref[..., c:2 * c].view(b, tp, heads, hd).permute(0, 2, 1, 3)
+    rv = ref[..., 2 * c:].view(b, tp, heads, hd).permute(0, 2, 3, 1)
+    tol = {torch.float16: 6e-3, torch.bfloat16: 5e-2}[dtype]
+    for got, want, name, tdim in ((q, rq, "q", 2), (k, rk, "k", 2), (vt, rv, "vt", 3)):
+        got = got.float().cpu()
+        assert torch.isfinite(got).all(), name
+        d = (got - want).abs()
+        d = d[:, :, valid] if tdim == 2 else d[..., valid]
+        err = d.max().item() / want.abs().max().item()
+        assert err < tol, (name, err)
