@@ -20,6 +20,8 @@ def bench_name(k):
     """rocprof kernel symbol -> bench.py / prof.hip kernel class (None = not one of ours)."""
     if "vitblock_kernel" in k:
         return "vit_block"
+    if "vit_stem_kernel" in k:
+        return "vit_stem"
     if "vit_qkv_kernel" in k:
         return "vit_qkv"
     if "enc_chain_kernel" in k:
