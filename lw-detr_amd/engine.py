@@ -729,7 +729,7 @@ class ForwardPlan:
         the launch chains of ``LWDETR._forward_chains`` fill one set of output tensors, no concatenation afterwards."""
         B, S, d, nq, T = self.B, self.S, self.d, self.nq, self.T
         stream = K._nat.stream_ptr(self.dev)
-        if images.dtype == T and images.is_contiguous() and images.device == self.x.device:
+        if images.dtype == T and images.is_contiguous() and images.device == self.x.device and images.data_ptr() % 16 == 0:
             self._img_ref = images                                   # the patch GEMM reads the caller's tensor in place
         else:
             if self.images is None:
