@@ -304,7 +304,7 @@ def main():
         return _cpu_baseline_worker(a)
     if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         return self_launch(a)                       # started plainly: become the launcher of N ranks
-    rank, world, local = ldist.init_from_env()
+    rank, world, local = ldist.init_from_env(rccl_log=True)      # opt-in: config.rccl reports the channel transports
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {world} rank(s); refusing to report")
     if a.launch_check:

@@ -1075,7 +1075,6 @@ ChainLayout chain_layout(const lwdetr_chain_desc* d) {
         L.bias_off[i] = (int)off;
         if (s.kind == LWDETR_CHAIN_FULL) {
             const int k = (i == 0) ? d->k_in : d->D;
-            if (i > 0 && d->k_in != d->D && false) return L;
             L.nt[i] = d->D / 32;
             off += d->D;
             if (s.flags & LWDETR_CHAIN_LN) { L.gam_off[i] = (int)off; off += d->D; L.bet_off[i] = (int)off; off += d->D; }
@@ -1133,7 +1132,7 @@ extern "C" int lwdetr_row_chain(const lwdetr_chain_desc* d, int dtype, void* hip
             if (s.flags & LWDETR_CHAIN_ADDQ) uses_q = true;
             flops += 2.0 * d->M * d->D * (i == 0 ? d->k_in : d->D);
         } else {
-            if (s.flags & ~0) { if (s.flags != 0) return LWDETR_ERR_BAD_ARG; }
+            if (s.flags) return LWDETR_ERR_BAD_ARG;          // a SIDE stage takes no flags
             flops += 2.0 * d->M * d->D * 32.0 * L.nt[i];
         }
     }

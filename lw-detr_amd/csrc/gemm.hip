@@ -978,15 +978,30 @@ extern "C" int lwdetr_debug_big_timing(unsigned long long* out) {
 }
 #define BIG_NOW() __builtin_amdgcn_s_memrealtime()
 #endif
-template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d) {
+// Round 5: the same kernel with NW = 4 waves on a BM = 128 row tile (wave tiles unchanged: 128 x 64 at BN = 256, 64 x 96 at BN = 192),
+// 32-deep stages in a 3-deep ring = 72 / 60 KB of LDS and <= 256 registers: TWO workgroups per CU. A K = 768 tile of the 8-wave
+// form spends a third of its time in its prologue (first stages on their way from HBM, every workgroup of the chip at once) and its
+// epilogue (256 KB through LDS, 128 KB of stores) with the CU's matrix pipes idle; with a second, independent workgroup on the CU
+// one tile's epilogue / prologue runs beside the other's k-loop (profiles/r5a_*).
+template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN, int BM = 256, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const lwdetr_gemm_desc d, const int stagger) {
     static_assert(sizeof(T) == 2, "16-bit types only");
-    constexpr int BM = 256, EPC = 8;
-    constexpr int WGN = BN == 256 ? 4 : 2, WGM = 8 / WGN;         // wave grid: 2 x 4 (BN 256) or 4 x 2 (BN 192 / 128)
+    // Start skew (tuning, LWDETR_GEMM_BIG_STAGGER = groups * 1000 + microseconds-tenths per group): all tiles of a launch take the
+    // same time, so the workgroups of a round reach their prologue (HBM reads) and their epilogue (128 KB of stores each) together
+    // and those phases run at the chip's HBM rate with idle matrix pipes. Delaying the first round's workgroups group by group
+    // spreads the phases for the rest of the launch (later workgroups start whenever a CU falls free).
+    if (stagger > 0 && blockIdx.x < 256) {
+        const int groups = stagger / 1000, tenths = stagger % 1000;
+        const int g = (blockIdx.x >> 3) % groups;                  // CU-level index inside the XCD (block b runs on XCD b % 8)
+        for (int i = 0; i < g * tenths; ++i) __builtin_amdgcn_s_sleep(3);      // 3 x 64 clocks = 0.09 us at 2.1 GHz: ~0.1 us per round
+    }
+    static_assert((NW == 8 && BM == 256) || (NW == 4 && BM == 128), "8 waves x 256 rows or 4 waves x 128 rows");
+    constexpr int EPC = 8;
+    constexpr int WGN = BN == 256 ? 4 : 2, WGM = NW / WGN;        // wave grid: 2 x 4 (BN 256) or 4 x 2 (BN 192 / 128); NW = 4: 1 x 4 / 2 x 2
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    static_assert(WN % 32 == 0 && (BN / (64 / (KB / 8))) % 8 == 0, "tile / stage combination not supported");
+    static_assert(WN % 32 == 0 && WM % 64 == 0 && (BN / (64 / (KB / 8))) % NW == 0 && (BM / (64 / (KB / 8))) % NW == 0, "tile / stage combination not supported");
     constexpr int SLOTS = KB / EPC, RP = 64 / SLOTS, KC = KB / 16;
-    constexpr int A_MY = BM / RP / 8, B_MY = BN / RP / 8, PER_STAGE = A_MY + B_MY;
+    constexpr int A_MY = BM / RP / NW, B_MY = BN / RP / NW, PER_STAGE = A_MY + B_MY;
     constexpr int STAGE = (BM + BN) * KB;                         // elements
     typedef typename Vec<T>::v8 V8;
     extern __shared__ __attribute__((aligned(16))) char big_smem[];
@@ -1016,13 +1031,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
     // they cost ~100 issue cycles each with both waves of a SIMD stalled behind them (kb64: 8 pieces per wave and stage).
     const int prow = lane / SLOTS, pslot = lane % SLOTS;
     auto key_of = [](int row) { return KB == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
-    // Piece kk of an operand covers tile rows RP (wave + 8 kk) + prow: 8 RP rows further per piece, and the swizzle key of
-    // those rows does not depend on kk (8 RP is a multiple of the key period) - so a lane keeps ONE base offset per operand
+    // Piece kk of an operand covers tile rows RP (wave + NW kk) + prow: NW RP rows further per piece, and the swizzle key of
+    // those rows does not depend on kk (NW RP is a multiple of the key period) - so a lane keeps ONE base offset per operand
     // and adds the wave-uniform piece / stage displacement when it issues (the round-1 kernel kept a pointer and a step per
     // piece: 24 registers the accumulators need).
     const int row0 = RP * wave + prow;
     const int swz = (pslot ^ key_of(row0)) * EPC;
-    static_assert((8 * RP) % 16 == 0, "piece stride must preserve the swizzle key");
+    static_assert((NW * RP) % 16 == 0, "piece stride must preserve the swizzle key");
     const long a_row0 = m0 + row0, w_row0 = (long)n0 + row0;
     const long a_off0 = a_row0 * d.lda + swz, w_off0 = w_row0 * (long)d.K + swz;
     // implicit-GEMM 3x3 view (AMODE CONV3x3): A row = output pixel (b, y, x); stage k0 reads channels k0 % Cin .. of the input
@@ -1033,7 +1048,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
     if (AMODE == LWDETR_A_CONV3x3) {
 #pragma unroll
         for (int k = 0; k < A_MY; ++k) {
-            const long gr = a_row0 + 8 * RP * k;
+            const long gr = a_row0 + NW * RP * k;
             const int hw = d.conv_hout * d.conv_wout;
             const int b = (int)(gr / hw), r = (int)(gr - (long)b * hw), y = r / d.conv_wout, x = r - y * d.conv_wout;
             cv_pix[k] = gr < d.M ? (b << 20) | (y << 10) | x : -1;
@@ -1047,7 +1062,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
     auto issue_piece = [&](int kt, int k) {
         const bool is_a = k < A_MY;
         const unsigned dst = lds0 + (unsigned)((kt % NST) * STAGE + (is_a ? 0 : BM * KB)) * (unsigned)sizeof(T) + wave_off +
-                             (unsigned)(8 * (is_a ? k : k - A_MY) * 64 * EPC * (int)sizeof(T));
+                             (unsigned)(NW * (is_a ? k : k - A_MY) * 64 * EPC * (int)sizeof(T));
         const int kk = is_a ? k : k - A_MY;
         const T* src;
         if (AMODE == LWDETR_A_CONV3x3 && is_a) {
@@ -1060,8 +1075,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
             }
             src = (kt < nk && cv_src[kk]) ? cv_src[kk] + c0 : zero;
         } else {
-            const long disp = (long)(8 * RP * kk) * (is_a ? (long)d.lda : (long)d.K) + (long)kt * KB;       // wave-uniform
-            const bool ok = kt < nk && (is_a ? a_row0 + 8 * RP * kk < d.M : w_row0 + 8 * RP * kk < (long)d.N);
+            const long disp = (long)(NW * RP * kk) * (is_a ? (long)d.lda : (long)d.K) + (long)kt * KB;       // wave-uniform
+            const bool ok = kt < nk && (is_a ? a_row0 + NW * RP * kk < d.M : w_row0 + NW * RP * kk < (long)d.N);
             src = ok ? (is_a ? A + a_off0 : W + w_off0) + disp : zero;
         }
         const unsigned m0v = __builtin_amdgcn_readfirstlane(dst);
@@ -1185,7 +1200,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
         // staging in each: 9-12 us per tile, a third of a K = 768 tile's time; a register-direct epilogue - permlane32
         // swaps to 16-byte runs, no LDS - measured slower, 14-19 us: its stores touch 32 rows x 32 bytes per instruction).
         // 32x32 accumulator: register 4 q + r of lane (c = lane & 31, hi) is element (row 8 q + 4 hi + r, column c) of D.
-        constexpr int EPI_PASSES = BN == 128 ? 1 : 2, EPI_SLOTS = 4 / EPI_PASSES;
+        constexpr int EPI_PASSES = BN == 128 ? 1 : 2, EPI_SLOTS = (BM / 64) / EPI_PASSES;
 #pragma unroll 1
         for (int pass = 0; pass < EPI_PASSES; ++pass) {
 #pragma unroll
@@ -1214,7 +1229,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
 #endif
 #pragma unroll 1
             for (int slot = 0; slot < EPI_SLOTS; ++slot)       // not unrolled: the accumulators of the later passes are still live
-                epilogue_finish<T, BN, 512, 4>(d, sg, COL, stg + slot * (COL ? BN * SLD_T : 64 * SLD), m0 + (slot * EPI_PASSES + pass) * 64, n0);
+                epilogue_finish<T, BN, NW * 64, 4>(d, sg, COL, stg + slot * (COL ? BN * SLD_T : 64 * SLD), m0 + (slot * EPI_PASSES + pass) * 64, n0);
 #ifdef LWDETR_BIG_TIMING
             const unsigned long long t2_ = BIG_NOW();
 #endif
@@ -1236,10 +1251,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d)
     else body(std::false_type{});
 }
 
-template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
+template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN, int BM = 256, int NW = 8>
 int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
-    constexpr size_t ring = (size_t)NST * (256 + BN) * KB * sizeof(T);
-    constexpr size_t stg = (size_t)(BN == 128 ? 4 : 2) * (64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
+    constexpr size_t ring = (size_t)NST * (BM + BN) * KB * sizeof(T);
+    constexpr size_t stg = (size_t)((BM / 64) / (BN == 128 ? 1 : 2)) * (64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
     constexpr size_t lds = ring > stg ? ring : stg;
     // per device (a process may drive several GPUs); a device that refuses the 160 KB request keeps the 64 x 64 ring kernel:
     // LWDETR_ERR_UNSUPPORTED tells try_launch_big to fall through
@@ -1247,10 +1262,13 @@ int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_UNSUPPORTED;
     if (state[dev] == 0)
-        state[dev] = hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : -1;
+        state[dev] = hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST, AMODE, BM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         NW == 4 ? 80 * 1024 : 160 * 1024) == hipSuccess ? 1 : -1;
     if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
-    const long nwg = ((d.M + 255) / 256) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(512), lds, st, d);
+    static_assert(NW == 8 || lds <= 80 * 1024, "two workgroups per CU");
+    const long nwg = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    const char* sg_env = getenv("LWDETR_GEMM_BIG_STAGGER");
+    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE, BM, NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, d, sg_env ? atoi(sg_env) : 0);
     return lwdetr_check_launch();
 }
 
@@ -1261,6 +1279,13 @@ int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
 // LWDETR_GEMM_BIG / lwdetr_gemm_tuning(): 0 = never, 1 = default thresholds, 2 = whenever legal (tests), 32 / 64 = whenever
 // legal with that stage depth (tuning).
 int g_big_mode = -1;
+// Shapes on which the 4-wave / 128-row form (two workgroups per CU) measured faster than the 8-wave 256-row one
+// (profiles/r5a_gemm_big_2wg.txt): placeholder until measured - short k-loops, where prologue + epilogue are a large share of a tile.
+template <int AMODE>
+bool big_2wg_pays(const lwdetr_gemm_desc& d, int bn) {
+    (void)bn;
+    return d.K <= 1024 && AMODE == LWDETR_A_PLAIN;
+}
 template <typename T, int AMODE>
 int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
     taken = false;
@@ -1282,10 +1307,15 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
         for (int s = 0; s < d.nseg; ++s) if (d.seg[s].n_begin % bn != 0) return LWDETR_OK;
         const long tiles = ((d.M + 255) / 256) * ((d.N + bn - 1) / bn);
         if (mode == 1 && !(d.K >= 384 && d.N >= 192 && (d.M >= 16384 || (d.K >= 960 && tiles >= 96)))) return LWDETR_OK;
-        const int variant = mode >= 10 ? mode : 0;     // tuning: 32 / 64 = stage depth (ring 4 / 2 deep)
+        const int variant = mode >= 10 ? mode : 0;     // tuning: 32 / 64 = stage depth (ring 4 / 2 deep), 128 = the 4-wave 128-row form
+        // 4-wave / 128-row form (two workgroups per CU): LWDETR_GEMM_BIG_2WG = 0 never, 1 where it measured faster (default), 2 whenever legal
+        const char* wg2_env = getenv("LWDETR_GEMM_BIG_2WG");            // read per launch: tests switch it inside one process
+        const int wg2_mode = wg2_env ? atoi(wg2_env) : 1;
+        const bool wg2 = variant == 128 || (variant == 0 && (wg2_mode == 2 || (wg2_mode == 1 && big_2wg_pays<AMODE>(d, bn))));
         int rc;
-        if (bn == 256) rc = variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st);
-        else if (bn == 192) rc = launch_big<T, 192, 64, 2, AMODE>(d, st);
+        if (bn == 256) rc = wg2 ? launch_big<T, 256, 32, 3, AMODE, 128, 4>(d, st)
+                                : (variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st));
+        else if (bn == 192) rc = wg2 ? launch_big<T, 192, 32, 3, AMODE, 128, 4>(d, st) : launch_big<T, 192, 64, 2, AMODE>(d, st);
         else rc = variant == 32 ? launch_big<T, 128, 32, 4, AMODE>(d, st) : launch_big<T, 128, 64, 3, AMODE>(d, st);
         taken = rc != LWDETR_ERR_UNSUPPORTED;          // refused LDS size: the caller launches the ring kernel instead
         return taken ? rc : LWDETR_OK;

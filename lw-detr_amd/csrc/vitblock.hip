@@ -133,8 +133,8 @@ __device__ __forceinline__ float gelu_s1(float x, float x2, float p) {
 }
 __device__ __forceinline__ float gelu_s2(float x, float e) { return x * __builtin_amdgcn_rcpf(1.f + e); }
 
-template <typename T, int C, int NH, bool QKV>
-__global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
+template <typename T, int C, int NH, bool QKV, int WPC = 1>
+__global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
     typedef typename Vec<T>::v8 V8;
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int KS = C / 16;                  // k-steps of a K = C contraction = fragments per piece
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void vitblock_kernel(const VbParams p) {
     constexpr int NCH = C / 8;                  // hidden chunks of 32 units (4C / 32)
     constexpr int PIECE_B = KS * 1024;          // bytes per piece
     constexpr int DPW = KS / 4;                 // DMA wave-instructions per piece and wave
-    constexpr int NSLOT = C == 192 ? 8 : 5;     // ring depth in pieces
+    constexpr int NSLOT = WPC == 2 ? 5 : (C == 192 ? 8 : 5);     // ring depth in pieces (WPC = 2: two workgroups per CU, 72 KB each)
     constexpr int VEC_F = 13 * C;
     constexpr int VEC_B = (VEC_F * 4 + 4095) / 4096 * 4096, VEC_DPW = VEC_B / 4096;
     constexpr int NP_PROJ = NTI, NP_HID = 2 * NCH, NP_QKV = QKV ? 3 * NTI : 0, NP = NP_PROJ + NP_HID + NP_QKV;
@@ -1252,9 +1252,9 @@ int launch_vs(const VsParams& p, hipStream_t st) {
 
 struct VbLaunchState { bool attr_done; int ncu; };
 
-template <typename T, int C, int NH, bool QKV>
+template <typename T, int C, int NH, bool QKV, int WPC = 1>
 int launch_vb(const VbParams& p, hipStream_t st) {
-    constexpr int KS = C / 16, PIECE_B = KS * 1024, NSLOT = C == 192 ? 8 : 5;
+    constexpr int KS = C / 16, PIECE_B = KS * 1024, NSLOT = WPC == 2 ? 5 : (C == 192 ? 8 : 5);
     constexpr int VEC_B = (13 * C * 4 + 4095) / 4096 * 4096;
     constexpr size_t lds = (size_t)NSLOT * PIECE_B + VEC_B;
     static VbLaunchState state[16] = {};
@@ -1262,7 +1262,7 @@ int launch_vb(const VbParams& p, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
     VbLaunchState& s = state[dev];
     if (!s.attr_done) {
-        if (hipFuncSetAttribute((const void*)vitblock_kernel<T, C, NH, QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)vitblock_kernel<T, C, NH, QKV, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LWDETR_ERR_LAUNCH;
@@ -1283,12 +1283,26 @@ int launch_vb(const VbParams& p, hipStream_t st) {
     while (((p.M / 8 + grid * 4 - 1) / (grid * 4)) * 8 > 32 * NH) ++grid;
     ProfScope ps(KID_VITBLOCK, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C,
                  (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T) + (p.out2 ? 1.0 : 0.0) * p.M * C * sizeof(T), st);
-    hipLaunchKernelGGL((vitblock_kernel<T, C, NH, QKV>), dim3((unsigned)grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((vitblock_kernel<T, C, NH, QKV, WPC>), dim3((unsigned)grid), dim3(256), lds, st, p);
     return lwdetr_check_launch();
 }
 
 template <typename T>
 int dispatch_vb(const VbParams& p, int C, bool qkv, hipStream_t st) {
+    // C = 192, 32 tokens per wave (128 per workgroup, <= 256 registers, 72 KB of LDS: two workgroups per CU) while all of the launch's
+    // workgroups are resident at once (M <= 65 536 rows on 256 CUs). Round 5, profiles/r5b_vitblock_half_tiles.txt: the launch's time is
+    // one workgroup's latency either way - 84 -> 67 us at M = 25 600 (one launch chain of config 2: 200 workgroups, one per CU), equal at
+    // M = 51 200 (400 workgroups, two per CU: 93.7 vs 92 us) - and its waves leave half of each SIMD's registers to the other chain's
+    // kernels: config 2 +1.3 % (two A/B pairs on one box). LWDETR_VB_HALF=0|1 forces either form (read per launch: tests switch it).
+    if (C == 192) {
+        const char* half_env = getenv("LWDETR_VB_HALF");
+        int dev = 0; (void)hipGetDevice(&dev);
+        static int ncu[16] = {};
+        if (dev >= 0 && dev < 16 && ncu[dev] == 0) { hipDeviceProp_t prop; ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+        const long cus = dev >= 0 && dev < 16 ? ncu[dev] : 256;
+        const bool half = half_env ? atoi(half_env) == 1 : (p.M + 127) / 128 <= 2 * cus;
+        if (half) return qkv ? launch_vb<T, 192, 1, true, 2>(p, st) : launch_vb<T, 192, 1, false, 2>(p, st);
+    }
     if (C == 192) return qkv ? launch_vb<T, 192, 2, true>(p, st) : launch_vb<T, 192, 2, false>(p, st);
     if (C == 384) return qkv ? launch_vb<T, 384, 1, true>(p, st) : launch_vb<T, 384, 1, false>(p, st);
     return LWDETR_ERR_UNSUPPORTED;

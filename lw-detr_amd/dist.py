@@ -9,29 +9,39 @@ pickle -> ByteTensor -> padded ``all_gather`` -> unpickle of per-image results (
 import glob
 import os
 import re
+import shutil
 import sys
 import tempfile
 
-# The ROCm host driver of the MI355X pool supports dmabuf IPC only: RCCL's intra-node peer-to-peer setup over xGMI
-# (hipIpcGetMemHandle / hipIpcOpenMemHandle between the ranks of a node) fails with "invalid argument" in the legacy IPC mode.
-# The HSA runtime reads this when it starts (the first device call of the process), so it is set on import - before torch has
-# touched the GPU in any process that imports lwdetr_amd.dist first (bench.py sets it before `import torch` as well) - and never
-# over a value the caller chose. init_from_env() warns when the runtime was already up without it.
-_IPC_ENV_PRESET = "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch
+import torch.distributed as dist
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-_RCCL_LOG = None        # NCCL_DEBUG_FILE pattern of this job when init_from_env switched the RCCL init log on
+_RCCL_LOG = None        # NCCL_DEBUG_FILE pattern of this job when init_from_env(rccl_log=True) switched the RCCL init log on
+_RCCL_LOG_DIR = None    # its private directory (removed by rccl_report)
 
 
-def init_from_env(backend=None, single_node=None, force=None):
+def ensure_dmabuf_ipc():
+    """The ROCm host driver of the MI355X pool supports dmabuf IPC only: RCCL's intra-node peer-to-peer setup over xGMI
+    (hipIpcGetMemHandle / hipIpcOpenMemHandle between the ranks of a node) fails with "invalid argument" in the legacy IPC mode.
+    The HSA runtime reads HSA_ENABLE_IPC_MODE_LEGACY when it starts (the first device call of the process), so the default must be
+    in place BEFORE that: launchers (bench.py) call this - or export the variable - before their first device call; init_from_env()
+    calls it for ``nccl`` groups and warns when the runtime was already up. Never overrides a value the caller chose. Returns True
+    when the variable is in place in time (already exported, or set now with the GPU runtime still down)."""
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+        return True
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return not (torch.cuda.is_available() and torch.cuda.is_initialized())
+
+
+def init_from_env(backend=None, single_node=None, force=None, rccl_log=False):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
     Returns (rank, world_size, local_rank). Without a launcher environment (no RANK) a single process is a no-op returning
     (0, 1, 0); under a launcher the process group is created even for WORLD_SIZE=1 (``force`` overrides either way), so a
     one-rank ``torchrun`` exercises the same backend initialisation (RCCL on a GPU box) as an N-rank job.
-    ``single_node`` (default: inferred from LOCAL_WORLD_SIZE == WORLD_SIZE) gates the loopback-only RCCL bootstrap."""
+    ``single_node`` (default: inferred from LOCAL_WORLD_SIZE == WORLD_SIZE) gates the loopback-only RCCL bootstrap.
+    ``rccl_log`` (opt-in; bench.py): route RCCL's init log (NCCL_DEBUG=INFO) of this process into a private temporary directory so
+    that rccl_report() can say which transports the channels use; the directory is removed by rccl_report(). Nothing is written
+    and NCCL_DEBUG is left alone otherwise, or when the caller already set NCCL_DEBUG."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if force is None:
         force = "RANK" in os.environ and "MASTER_PORT" in os.environ
@@ -53,15 +63,16 @@ def init_from_env(backend=None, single_node=None, force=None):
                 if k not in os.environ:
                     os.environ[k] = v
                     print(f"[lwdetr_amd.dist] single-node job: {k}={v}", file=sys.stderr, flush=True)
-        if not _IPC_ENV_PRESET and torch.cuda.is_initialized():
-            print("[lwdetr_amd.dist] warning: the GPU runtime was initialised before lwdetr_amd.dist was imported and "
-                  "HSA_ENABLE_IPC_MODE_LEGACY was not exported; export HSA_ENABLE_IPC_MODE_LEGACY=0 for multi-rank RCCL on "
-                  "this driver (dmabuf IPC only)", file=sys.stderr, flush=True)
-        if "NCCL_DEBUG" not in os.environ:
+        if not ensure_dmabuf_ipc():
+            print("[lwdetr_amd.dist] warning: the GPU runtime was initialised before HSA_ENABLE_IPC_MODE_LEGACY was exported; "
+                  "call lwdetr_amd.dist.ensure_dmabuf_ipc() (or export HSA_ENABLE_IPC_MODE_LEGACY=0) before the first device call "
+                  "for multi-rank RCCL on this driver (dmabuf IPC only)", file=sys.stderr, flush=True)
+        if rccl_log and "NCCL_DEBUG" not in os.environ:
             # RCCL's init log (version, topology, the transport of every channel) into a per-process file: rccl_report() reads
-            # rank 0's copy after the run so that the bench line can show "P2P over xGMI only". INFO logs at init / connect only.
-            global _RCCL_LOG
-            _RCCL_LOG = os.path.join(tempfile.gettempdir(), f"lwdetr_rccl_{os.environ.get('MASTER_PORT', '0')}")
+            # this process's copy after the run so that the bench line can show "P2P over xGMI only". INFO logs at init / connect only.
+            global _RCCL_LOG, _RCCL_LOG_DIR
+            _RCCL_LOG_DIR = tempfile.mkdtemp(prefix="lwdetr_rccl_")
+            _RCCL_LOG = os.path.join(_RCCL_LOG_DIR, "rccl")
             os.environ["NCCL_DEBUG"] = "INFO"
             os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,P2P,SHM,NET")
             os.environ["NCCL_DEBUG_FILE"] = _RCCL_LOG + ".%p.log"
@@ -75,29 +86,35 @@ def parse_rccl_log(text):
     """RCCL / NCCL INFO log -> {"version", "channels_p2p", "channels_shm", "channels_net", "xgmi_only"}: the `... via P2P/IPC`
     (xGMI / PCIe peer access), `via SHM` (host memory bounce) and `via NET` (sockets / IB) channel lines of the connect phase."""
     ver = re.search(r"(?:RCCL|NCCL) version ([0-9][^\s]*)", text)
-    p2p = len(re.findall(r"via P2P/", text))
-    shm = len(re.findall(r"via SHM", text))
-    net = len(re.findall(r"via NET/", text))
+    chan = [ln for ln in text.splitlines() if re.search(r"\bChannel \d+(?:/\d+)? : ", ln)]     # connect-phase lines only
+    p2p = sum(1 for ln in chan if "via P2P/" in ln)
+    shm = sum(1 for ln in chan if "via SHM" in ln)
+    net = sum(1 for ln in chan if "via NET/" in ln)
     return {"version": ver.group(1) if ver else None, "channels_p2p": p2p, "channels_shm": shm, "channels_net": net,
             "xgmi_only": bool(p2p) and not shm and not net}
 
 
 def rccl_report():
-    """What this process's RCCL saw (bench.py prints it for N > 1): library version as torch reports it, and - when init_from_env
-    switched the init log on - the transports of the channels this rank connected."""
+    """What this process's RCCL saw (bench.py prints it for N > 1): library version as torch reports it, and - when
+    init_from_env(rccl_log=True) switched the init log on - the transports of the channels this rank connected. Removes the
+    temporary log directory (call it once, after the collectives have run)."""
+    global _RCCL_LOG, _RCCL_LOG_DIR
     rep = {"torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.cuda.is_available() else None,
            "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "NCCL_P2P_DISABLE")}}
     if not _RCCL_LOG:
-        rep["log"] = f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG')} was set by the caller: RCCL's init log is where the caller sent it"
-    if _RCCL_LOG:
-        text = ""
-        for fp in glob.glob(_RCCL_LOG + f".{os.getpid()}.log"):
-            try:
-                text += open(fp, errors="replace").read()
-            except OSError:
-                pass
-        rep.update(parse_rccl_log(text))
-        rep["log"] = "NCCL_DEBUG=INFO init log of rank 0" if text else "no RCCL log found"
+        rep["log"] = (f"NCCL_DEBUG={os.environ.get('NCCL_DEBUG')} was set by the caller: RCCL's init log is where the caller sent it"
+                      if os.environ.get("NCCL_DEBUG") else "RCCL init log not requested (init_from_env(rccl_log=True))")
+        return rep
+    text = ""
+    for fp in glob.glob(_RCCL_LOG + f".{os.getpid()}.log"):
+        try:
+            text += open(fp, errors="replace").read()
+        except OSError:
+            pass
+    rep.update(parse_rccl_log(text))
+    rep["log"] = "NCCL_DEBUG=INFO init log of rank 0" if text else "no RCCL log found"
+    shutil.rmtree(_RCCL_LOG_DIR, ignore_errors=True)
+    _RCCL_LOG = _RCCL_LOG_DIR = None
     return rep
 
 

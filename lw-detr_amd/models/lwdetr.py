@@ -96,7 +96,7 @@ class LWDETR(nn.Module):
                 raise _native.NativeError(f"lwdetr_amd: all parameters must share one dtype and device (found {mixed})")
             _native.lib()       # raises loudly when the extension is missing
             self._packed = (tok, PackedWeights(dict(self.state_dict()), self._args, dev, dt))
-            self._plans = {}
+            self._plans = PlanCache()
         return self._packed
 
     def _plan(self, b, h, w, private=False, slot=0):
@@ -107,17 +107,12 @@ class LWDETR(nn.Module):
         if private:
             with torch.cuda.device(tok[0]):
                 return ForwardPlan(pw, b, h, w)
-        if key in self._plans:
-            self._plans[key] = self._plans.pop(key)          # LRU: most recently used last
-            return self._plans[key]
-        # room for 4 batch shapes, each with all of its launch chains (a shape's chains are evicted together, oldest shape first)
-        shapes = list(dict.fromkeys(k[:3] for k in self._plans))
-        if key[:3] not in shapes and len(shapes) >= 4:
-            for k in [k for k in self._plans if k[:3] == shapes[0]]:
-                self._plans.pop(k)
-        with torch.cuda.device(tok[0]):
-            self._plans[key] = ForwardPlan(pw, b, h, w)
-        return self._plans[key]
+        def build():
+            with torch.cuda.device(tok[0]):
+                return ForwardPlan(pw, b, h, w)
+        # bounded by the TOTAL number of resident plans (default 8, LWDETR_PLAN_CACHE): least recently used shape first, all launch
+        # chains of a shape together (lwdetr_amd/plan_cache.py; INTEGRATION.md section 6 for the memory this holds)
+        return self._plans.get(key, build)
 
     @torch.no_grad()
     def forward(self, samples, targets=None, _forced_topk=None, _collect=None):

@@ -172,14 +172,18 @@ def test_bench_self_launches_eight_ranks():
 
 
 def test_ipc_mode_is_exported_before_the_gpu_runtime_starts():
-    """bench.py and lwdetr_amd.dist export HSA_ENABLE_IPC_MODE_LEGACY=0 on import (dmabuf IPC: the only mode this driver has;
-    RCCL's xGMI peer-to-peer setup fails without it) and never override a caller's value."""
+    """bench.py exports HSA_ENABLE_IPC_MODE_LEGACY=0 before `import torch`, lwdetr_amd.dist.ensure_dmabuf_ipc() (called by
+    init_from_env for nccl groups) does it for other launchers (dmabuf IPC: the only mode this driver has; RCCL's xGMI peer-to-peer
+    setup fails without it) - never over a caller's value, and NOT as a side effect of importing the library."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
-    code = "import sys; sys.path.insert(0, %r); import os; import lwdetr_amd.dist; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "0"
+    code = ("import sys; sys.path.insert(0, %r); import os; import lwdetr_amd.dist as D; a = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'); "
+            "ok = D.ensure_dmabuf_ipc(); print(a, os.environ['HSA_ENABLE_IPC_MODE_LEGACY'], ok)" % ROOT)
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.split() == ["None", "0", "True"]
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1"
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.split() == ["1", "1", "True"]
+    bench_head = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench_head.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < bench_head.index("import torch")
     from lwdetr_amd import dist as D
     rep = D.parse_rccl_log("h:1:1 [0] NCCL INFO RCCL version 2.26.6-HEAD:x\nh:1:2 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\n"
                            "h:1:2 [0] NCCL INFO Channel 01/0 : 0[0] -> 7[7] via P2P/IPC\n")
@@ -202,3 +206,34 @@ def test_bench_refuses_world_size_mismatch():
     assert r.returncode != 0
     assert "refusing to report" in (r.stderr + r.stdout)
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_parse_rccl_log_on_an_eight_rank_init_log_sample():
+    """parse_rccl_log / the per-rank view of rccl_report on an 8-rank single-node init log in RCCL's INFO format
+    (tests/golden/rccl_init_8ranks_format_sample.log - a format sample assembled from the library's format strings, see its header;
+    the real two-rank log of the GPU box goes through the same parser in tests/test_gpu_dist.py), plus the SHM / NET / mixed cases."""
+    from lwdetr_amd import dist as D
+    text = open(os.path.join(ROOT, "tests", "golden", "rccl_init_8ranks_format_sample.log")).read()
+    rep = D.parse_rccl_log(text)
+    assert rep["version"] == "2.26.6-HEAD:1a2b3c4" and rep["channels_p2p"] == 8 * 2 * 2 and rep["channels_shm"] == 0 and rep["channels_net"] == 0
+    assert rep["xgmi_only"]
+    rank3 = "\n".join(ln for ln in text.splitlines() if " [3] " in ln)             # what rank 3's own NCCL_DEBUG_FILE holds
+    r3 = D.parse_rccl_log(rank3)
+    assert r3["channels_p2p"] == 4 and r3["xgmi_only"] and r3["version"].startswith("2.26.6")
+    # "NET/Socket : Using ..." and "NET/Plugin" lines of the bootstrap are not channels
+    assert D.parse_rccl_log("x NCCL INFO NET/Socket : Using [0]lo:127.0.0.1<0>\nx NCCL INFO NET/Plugin: none")["channels_net"] == 0
+    mixed = rank3 + "\nh:1:2 [3] NCCL INFO Channel 02/0 : 3[3] -> 4[4] [send] via NET/Socket/0\n"
+    assert D.parse_rccl_log(mixed)["channels_net"] == 1 and not D.parse_rccl_log(mixed)["xgmi_only"]
+    shm = rank3.replace("via P2P/IPC/read", "via SHM/direct/direct")
+    assert D.parse_rccl_log(shm)["channels_shm"] == 4 and not D.parse_rccl_log(shm)["xgmi_only"]
+    assert D.parse_rccl_log("")["xgmi_only"] is False and D.parse_rccl_log("")["version"] is None
+
+
+def test_rccl_init_log_is_opt_in():
+    """init_from_env leaves NCCL_DEBUG alone and writes nothing unless rccl_log=True (advisor r4); rccl_report says so."""
+    import subprocess
+    code = ("import sys, os; sys.path.insert(0, %r); os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533'); "
+            "os.environ.pop('NCCL_DEBUG', None); import lwdetr_amd.dist as D; D.init_from_env('gloo'); "
+            "print('NCCL_DEBUG' in os.environ, D._RCCL_LOG, D.rccl_report()['log'])" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout
+    assert out.strip().splitlines()[-1].startswith("False None RCCL init log not requested"), out

@@ -21,12 +21,13 @@ def _free_port():
     return p
 
 
-def _torchrun(args, timeout=600):
+def _torchrun(args, timeout=600, nproc=1, env_extra=None):
     env = dict(os.environ)
     env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)      # bench.py / lwdetr_amd.dist set it themselves (dmabuf IPC)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -57,3 +58,25 @@ def test_bench_under_torchrun_one_rank_initialises_rccl():
     assert rccl.get("version") or "set by the caller" in rccl.get("log", ""), rccl
     with open(os.path.join(ROOT, "gpurun_out", "bench_torchrun_one_rank.json"), "w") as f:
         f.write(json.dumps(d) + "\n")
+
+
+def test_two_ranks_on_the_one_gpu_is_recorded():
+    """everything about an N > 1 `nccl` group that can run on a one-GPU box. Two ranks, both on GPU 0, through
+    init_from_env + all_gather_into_tensor: RCCL either serves them (then the gathered tensor is checked and the channel transports
+    of a real two-rank init log go through parse_rccl_log) or refuses a communicator with two ranks on one device - the exact
+    refusal is recorded (gpurun_out/rccl_two_ranks_one_gpu.log -> profiles/). Anything else (a hang, another error) fails."""
+    try:
+        r = _torchrun([os.path.join(ROOT, "tests", "rccl_two_ranks_one_gpu_driver.py")], timeout=240, nproc=2,
+                      env_extra={"CUDA_VISIBLE_DEVICES": "0", "HIP_VISIBLE_DEVICES": "0"})
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("two ranks on one GPU: no answer in 240 s (hang): " + str(e.stderr)[-1500:])
+    text = r.stdout + r.stderr
+    ok = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL2-OK")]
+    refused = [ln for ln in text.splitlines() if "Duplicate GPU detected" in ln or "invalid usage" in ln.lower() or "ncclInvalidUsage" in ln]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_two_ranks_one_gpu.log"), "w") as f:
+        f.write(f"returncode {r.returncode}\n" + "\n".join(ok) + "\n--- refusal lines ---\n" + "\n".join(refused[:8]) + "\n--- stderr tail ---\n" + r.stderr[-3000:] + "\n")
+    if r.returncode == 0:
+        assert len(ok) == 2, text[-3000:]
+    else:
+        assert refused, text[-4000:]

@@ -132,10 +132,13 @@ def test_gemm_conv3x3(dtype, stride, winmajor):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("stride,winmajor,cout", [(1, False, 192), (2, True, 384), (1, True, 128), (2, False, 256)])
-def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, big_gemm):
+@pytest.mark.parametrize("wg2", ["0", "2"])
+def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, wg2, big_gemm, monkeypatch):
     """The implicit-GEMM 3x3 view on the 256-row large-tile kernel (column tiles 192 / 128 / 256), zero padding at the image
-    border, stride 1 | 2, raster and window-major inputs, a channel window inside wider rows - vs F.conv2d."""
+    border, stride 1 | 2, raster and window-major inputs, a channel window inside wider rows - vs F.conv2d. wg2 = 2: the 4-wave
+    128-row form of the kernel (column tiles 256 / 192) wherever it is legal."""
     from lwdetr_amd import kernels as K
+    monkeypatch.setenv("LWDETR_GEMM_BIG_2WG", wg2)
     b, hp, wp, cin, ctot, col0 = 3, 24, 32, 128, 320, 64
     x = _rand(b, hp, wp, ctot, dtype=dtype, seed=1)
     w = _rand(cout, cin, 3, 3, dtype=dtype, scale=(9 * cin) ** -0.5, seed=2)
@@ -339,10 +342,13 @@ def big_gemm():
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("mnk,depth", [((1000, 768, 768), 2), ((4099, 256, 3072), 2), ((2048, 3072, 768), 64), ((777, 384, 384), 32),
                                        ((513, 128, 1536), 2), ((300, 640, 1024), 32), ((700, 576, 512), 2), ((1000, 192, 448), 2),
-                                       ((900, 1152, 384), 2)])
+                                       ((900, 1152, 384), 2),
+                                       # round 5: the 4-wave / 128-row form (two workgroups per CU; column tiles 256 and 192), ragged M / N tails
+                                       ((1000, 768, 768), 128), ((4099, 256, 3072), 128), ((2000, 2304, 768), 128), ((777, 192, 384), 128),
+                                       ((129, 1100, 448), 128), ((5000, 3072, 768), 128)])
 def test_gemm_large_tile_kernel(dtype, mnk, depth):
-    """gemm_big_kernel (256 x 256 / 256 x 128 tiles, 32x32x16 MFMA, DMA ring of 32- and 64-deep stages) vs torch: bias,
-    GELU, LayerScale + residual epilogue; ragged M and N tails."""
+    """gemm_big_kernel (256 x 256 / 256 x 128 tiles, 32x32x16 MFMA, DMA ring of 32- and 64-deep stages; depth 128 = the 4-wave
+    128 x 256 / 128 x 192 form) vs torch: bias, GELU, LayerScale + residual epilogue; ragged M and N tails."""
     from lwdetr_amd import _native, kernels as K
     m, n, k = mnk
     x = _rand(m, k, dtype=dtype, seed=1)
@@ -366,10 +372,13 @@ def test_gemm_large_tile_kernel(dtype, mnk, depth):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("hd", [64, 32, 16])
-def test_gemm_large_tile_kernel_head_layouts(dtype, hd, big_gemm):
-    """QKV of the C = 768 / 384 / 192 models through the large-tile kernel (column tiles 256 / 192 / 192): HEADS (q, k) and
-    HEADS_T (V^T, swapped MFMA operands)."""
+@pytest.mark.parametrize("wg2", ["0", "2"])
+def test_gemm_large_tile_kernel_head_layouts(dtype, hd, wg2, big_gemm, monkeypatch):
+    """QKV of the C = 768 / 384 / 192 models through the large-tile kernel (column tiles 256 / 192 / 192; wg2 = 2: its 4-wave
+    128-row form): HEADS (q, k) and HEADS_T (V^T, swapped MFMA operands)."""
+    monkeypatch.setenv("LWDETR_GEMM_BIG_2WG", wg2)
     _check_qkv_layouts(dtype, hd, 4, 1600)
+    _check_qkv_layouts(dtype, hd, 1, 1000)          # ragged last row tile (1000 = 7 x 128 + 104)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -507,12 +516,17 @@ def test_mlp_fused(dtype, c, m):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("c,heads,m,tp", [(192, 6, 51200, 1600), (192, 12, 12800, 400), (192, 3, 20000, 400), (192, 6, 64000, 1600),
                                           (384, 12, 25600, 1600), (384, 12, 12816, 4272), (192, 6, 13000, 1000)])
-def test_vit_block(dtype, c, heads, m, tp):
-    """lwdetr_vit_block (attention projection + LayerScale + residual, norm2 -> fc1 -> GELU -> fc2 -> LayerScale -> residual, and
+@pytest.mark.parametrize("half", ["0", "1"])
+def test_vit_block(dtype, c, heads, m, tp, half, monkeypatch):
+    """half = 1: the C = 192 form with 32 tokens per wave / two workgroups per CU (round 5; the default while all workgroups of a launch
+    are resident at once), half = 0: 64 tokens per wave. lwdetr_vit_block (attention projection + LayerScale + residual, norm2 -> fc1 -> GELU -> fc2 -> LayerScale -> residual, and
     norm1 + QKV of the next block, one launch) vs the torch fp32 formulation of vit.py:195-222 and vs lwdetr_mlp_fused on the
     same 16-bit weights. 51200 = BASELINE config 2 (32 images x 1600 tokens: 50 tokens per wave), 64000 / 25600 = more than one
     round of workgroups, 12816 / 13000 / 20000 = ragged token counts per wave and tiles that straddle images."""
     from lwdetr_amd import kernels as K
+    if c != 192 and half == "1":
+        pytest.skip("the half-tile form exists for C = 192 only")
+    monkeypatch.setenv("LWDETR_VB_HALF", half)
     hd = c // heads
     assert K.vit_block_supported(c, dtype, hd)
     x = _rand(m, c, dtype=dtype, seed=1) * 2 + 0.3

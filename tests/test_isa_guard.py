@@ -39,3 +39,21 @@ __global__ void k(float* o, f2 x, f2 b) {
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(obj)], stderr=subprocess.DEVNULL)
     r = subprocess.run([sys.executable, CHECK, str(obj)], capture_output=True, text=True)
     assert r.returncode == 1 and "crossed op_sel" in r.stderr, (r.returncode, r.stderr)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_guard_fails_closed(tmp_path):
+    """An object whose device code the guard cannot look at is an ERROR, not a pass (advisor r4): another --offload-arch than the
+    one the Makefile passes, or only host objects on the command line."""
+    src = tmp_path / "ok.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(float* o) { o[threadIdx.x] = 1.f; }\n")
+    obj = tmp_path / "ok.o"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx942", "-O3", "-c", str(src), "-o", str(obj)], stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, CHECK, "--arch", "gfx950", str(obj)], capture_output=True, text=True)
+    assert r.returncode == 2 and "no code object for" in r.stderr, (r.returncode, r.stderr)
+    assert subprocess.run([sys.executable, CHECK, "--arch", "gfx942", str(obj)], capture_output=True, text=True).returncode == 0
+    host = tmp_path / "host.o"
+    (tmp_path / "host.c").write_text("int f(void) { return 1; }\n")
+    subprocess.check_call(["gcc", "-c", str(tmp_path / "host.c"), "-o", str(host)])
+    r = subprocess.run([sys.executable, CHECK, str(host)], capture_output=True, text=True)
+    assert r.returncode == 2 and "nothing was checked" in r.stderr, (r.returncode, r.stderr)

@@ -17,22 +17,57 @@ LLVM = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 PAT = re.compile(r"\bv_pk_(fma|mul|add)_f32\b.*\bop_sel:\[")
 
 
-def device_disassembly(obj):
+class IsaCheckError(RuntimeError):
+    pass
+
+
+def device_disassembly(obj, arch):
+    """Disassembly of the object's device code for `arch`; "" only when the object has no .hip_fatbin section at all (a host-only
+    object). Anything else that keeps the check from LOOKING - an unbundle failure (renamed bundle id, another --offload-arch), an
+    empty disassembly - is an error: the guard fails closed (advisor r4)."""
     with tempfile.TemporaryDirectory() as td:
         fat, co = os.path.join(td, "a.fatbin"), os.path.join(td, "a.co")
-        if subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat]).returncode or not os.path.exists(fat) or os.path.getsize(fat) == 0:
+        sect = subprocess.run([f"{LLVM}/llvm-readelf", "-S", obj], capture_output=True, text=True)
+        if sect.returncode:
+            raise IsaCheckError(f"{obj}: cannot read section headers: {sect.stderr.strip()}")
+        if ".hip_fatbin" not in sect.stdout:
             return ""                                   # no device code in this object
-        r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
+        if subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat]).returncode or not os.path.exists(fat) or os.path.getsize(fat) == 0:
+            raise IsaCheckError(f"{obj}: has a .hip_fatbin section but objcopy could not extract it")
+        target = f"hipv4-amdgcn-amd-amdhsa--{arch}"
+        r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", f"--targets={target}", f"--input={fat}",
                             f"--output={co}", "--unbundle"], capture_output=True, text=True)
-        if r.returncode or not os.path.exists(co):
-            return ""
-        return subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], capture_output=True, text=True).stdout
+        if r.returncode or not os.path.exists(co) or os.path.getsize(co) == 0:
+            ids = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", f"--input={fat}", "--list"], capture_output=True, text=True).stdout.split()
+            raise IsaCheckError(f"{obj}: no code object for {target} in its fat binary (bundles: {ids}); pass the Makefile's ARCH (--arch)")
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], capture_output=True, text=True)
+        if dis.returncode or not re.search(r"^\s+[sv]_\w+", dis.stdout, re.M):
+            raise IsaCheckError(f"{obj}: llvm-objdump produced no instructions for the {target} code object")
+        return dis.stdout
 
 
-def main(objs):
+def main(argv):
+    arch = "gfx950"
+    objs = []
+    it = iter(argv)
+    for a in it:
+        if a == "--arch":
+            arch = next(it)
+        elif a.startswith("--arch="):
+            arch = a.split("=", 1)[1]
+        else:
+            objs.append(a)
     bad = 0
+    looked = 0
     for obj in objs:
-        dis = device_disassembly(obj)
+        try:
+            dis = device_disassembly(obj, arch)
+        except IsaCheckError as e:
+            print(f"check_isa: FAILED - {e}", file=sys.stderr)
+            return 2
+        if not dis:
+            continue
+        looked += 1
         hits = [ln.split("//")[0].strip() for ln in dis.splitlines() if PAT.search(ln)]
         packed = sum(1 for ln in dis.splitlines() if re.search(r"\bv_pk_(fma|mul|add)_f32\b", ln))
         if hits:
@@ -40,6 +75,9 @@ def main(objs):
             print(f"check_isa: {os.path.basename(obj)}: {len(hits)} packed-f32 instruction(s) with a crossed op_sel, e.g. `{hits[0]}`", file=sys.stderr)
         elif os.environ.get("CHECK_ISA_VERBOSE"):
             print(f"check_isa: {os.path.basename(obj)}: {packed} packed-f32 instructions, none with op_sel")
+    if objs and not looked:
+        print("check_isa: FAILED - none of the objects carries device code: nothing was checked", file=sys.stderr)
+        return 2
     if bad:
         print("check_isa: FAILED - build the object with -fno-slp-vectorize or rewrite the expression (DESIGN.md section 5d)", file=sys.stderr)
         return 1

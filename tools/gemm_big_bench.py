@@ -49,7 +49,8 @@ def main():
             fl = 2.0 * M * n * k
             row = f"{what:5s} N={n:5d} K={k:5d}:"
             ref = None
-            for mode, label in [(0, "ring64/128"), (64, "big kb64"), (32, "big kb32")]:
+            for mode, label in [(m_, l_) for m_, l_ in [(64, "big kb64"), (32, "big kb32"), (128, "4w128 2wg")]
+                                if str(m_) in os.environ.get("GEMM_BENCH_MODES", "64,32,128").split(",")]:
                 lib.lwdetr_gemm_tuning(mode)
                 us = timeit(op)
                 if ref is None:
