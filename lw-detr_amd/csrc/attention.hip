@@ -729,6 +729,11 @@ static bool lds_path_applies(const lwdetr_attn_desc& p) {
 // are free: row 16 is all ones, so the softmax denominator drops out of the same MFMAs. attn_kernel spreads a 100-key window
 // over 4 waves that each re-load K and V^T and run 4 dependent load -> MFMA -> softmax -> MFMA steps (19 us at B = 16 for
 // 40 MB of q / k / v / out, 2.4x the HBM floor; tools/attn_bench.py); here a wave issues all its loads at once.
+// Ablation builds for tuning (-DLWDETR_AW_ABL=bits, results are WRONG; never in the product): 1 = no output stores, 2 = no V^T loads,
+// 4 = no K / Q loads, 8 = no exp2 (profiles/r5c_*).
+#ifndef LWDETR_AW_ABL
+#define LWDETR_AW_ABL 0
+#endif
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_win_kernel(const lwdetr_attn_desc p) {
     typedef typename Vec<T>::v8 V8;
@@ -757,13 +762,25 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const lwdetr_attn_desc p)
     for (int kt = 0; kt < 4; ++kt) {
         int key = kt * 32 + l31; key = key < last ? key : last;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) kf[kt][c] = *(const V8*)(Kb + (long)key * HD + c * 16 + h * 8);
+        for (int c = 0; c < NC; ++c) {
+#if LWDETR_AW_ABL & 4
+            for (int e = 0; e < 8; ++e) kf[kt][c][e] = from_f32<T>(0.01f * (key + e));
+#else
+            kf[kt][c] = *(const V8*)(Kb + (long)key * HD + c * 16 + h * 8);
+#endif
+        }
     }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
         int q = qt * 32 + l31; q = q < last ? q : last;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) qf[qt][c] = *(const V8*)(Qb + (long)q * HD + c * 16 + h * 8);
+        for (int c = 0; c < NC; ++c) {
+#if LWDETR_AW_ABL & 4
+            for (int e = 0; e < 8; ++e) qf[qt][c][e] = from_f32<T>(0.02f * (q - e));
+#else
+            qf[qt][c] = *(const V8*)(Qb + (long)q * HD + c * 16 + h * 8);
+#endif
+        }
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -778,9 +795,13 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const lwdetr_attn_desc p)
                 // runs of 4 keys; a run past the end is clamped to the last run (finite values; its P is exactly 0)
                 int k0 = 16 * c + 4 * h, k1 = k0 + 8;
                 k0 = k0 + 4 <= nkeys ? k0 : nkeys - 4; k1 = k1 + 4 <= nkeys ? k1 : nkeys - 4;
+#if LWDETR_AW_ABL & 2
+                for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.03f * (row + k0 + e));
+#else
                 const V4 lo = *(const V4*)(Vb + (long)row * p.Tp + k0), hi = *(const V4*)(Vb + (long)row * p.Tp + k1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+#endif
             }
             vf[c][r] = v;
         }
@@ -830,7 +851,11 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const lwdetr_attn_desc p)
             V8 pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+#if LWDETR_AW_ABL & 8
+                const float pe = sc[c >> 1][8 * (c & 1) + e] - mx;
+#else
                 const float pe = __builtin_amdgcn_exp2f(sc[c >> 1][8 * (c & 1) + e] - mx);
+#endif
                 if (HD > 16) lsum += pe;
                 pf[e] = from_f32<T>(pe);
             }
@@ -860,7 +885,11 @@ __global__ __launch_bounds__(256) void attn_win_kernel(const lwdetr_attn_desc p)
                 const auto s1 = __builtin_amdgcn_permlane32_swap(lu[1], hu[1], false, false);
                 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
                 const u32x4v st = {s0[0], s1[0], s0[1], s1[1]};
+#if LWDETR_AW_ABL & 1
+                if (q < nkeys && p.B < 0)
+#else
                 if (q < nkeys)
+#endif
                     *(u32x4v*)(out + ((long)b * p.Tp + tok0 + q) * p.ldo + head * HD + r * 32 + 16 * bp + 8 * h) = st;
             }
         }
@@ -876,6 +905,172 @@ int launch_win(const lwdetr_attn_desc& p, hipStream_t st) {
     const int kid = p.kind == 0 ? KID_ATTN_WINDOW : (p.kind == 1 ? KID_ATTN_GLOBAL : KID_ATTN_DECODER);
     ProfScope ps(kid, flops, bytes, st);
     hipLaunchKernelGGL((attn_win_kernel<T, HD>), dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, st, p);
+    return lwdetr_check_launch();
+}
+
+// =====================================================================================================================
+// Window-tile variant (round 5; hd 16, windows of <= 128 keys - window attention of the C = 192 models at 640 x 640): ONE WORKGROUP
+// owns a whole (image, window) with all of its heads, and the window's tiles go through LDS:
+//   in : V^T of the window, all heads - (heads x 16) rows of `keys` values, 200-byte pieces of rows that lie 2 Tp bytes apart in
+//        memory - is staged in LDS by all 256 threads in coalesced 8-byte pieces (attn_win_kernel fetches them as MFMA fragments:
+//        14 load instructions per head with half the lanes idle, each touching 16 different lines); the A-operand fragments of
+//        O^T = V^T P^T are then conflict-free 8-byte LDS reads (row stride 52 dwords). Q and K of a (window, head) are contiguous
+//        3.2 KB runs already and stay direct register loads (whole 1 KB lines per instruction), prefetched one head ahead.
+//   out: every wave (heads w, w + 4, w + 8) writes its 16 channels of the window's rows into an LDS tile [keys][C]; after one
+//        barrier the workgroup stores the tile with full 16-byte-per-lane rows - the window's output is ONE contiguous run of
+//        keys x C x 2 bytes (window-major tokens, ldo = C) - instead of 32-byte pieces 2 C bytes apart per (token, head).
+// Arithmetic, masks and rounding points are attn_win_kernel's (the same MFMA sequence per (window, head)); results are bit-identical.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_wtile_kernel(const lwdetr_attn_desc p) {
+    constexpr int HD = 16;
+    typedef typename Vec<T>::v8 V8;
+    typedef typename Vec<T>::v4 V4;
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    static_assert(sizeof(T) == 2, "16-bit types");
+    extern __shared__ __attribute__((aligned(16))) char wt_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int w = (int)(blockIdx.x % (unsigned)p.seqs_per_img), b = (int)(blockIdx.x / (unsigned)p.seqs_per_img);
+    const long tok0 = (long)w * p.seq_tok_stride;
+    const int nkeys = p.keys_per_seq, last = nkeys - 1;
+    const int nvalid = p.sub_len < nkeys ? p.sub_len : nkeys;        // pad rows sit behind the real tokens (one sub-window)
+    const int nqt = (nkeys + 31) >> 5, nkt = (nvalid + 31) >> 5, nch = (nvalid + 15) >> 4;
+    const int C = p.heads * HD;
+    const int VLD = ((nkeys + 7) & ~7) + 8;                          // V^T row stride in elements: 104 + 8 = 56 dwords at 100 keys
+    const int OLD = C + 8;                                           // output tile row stride in elements (16-byte multiple)
+    T* vs = (T*)wt_smem;                                             // [heads * 16][VLD]
+    T* os = vs + (size_t)C * VLD;                                    // [nkeys][OLD]
+
+    // ---- Q / K of this wave's first head: issued before anything else
+    auto load_qk = [&](int head, V8 (&kf)[4], V8 (&qf)[4]) {
+        const long bh = (long)b * p.heads + head;
+        const T* __restrict__ Qb = (const T*)p.Q + (bh * p.Tp + tok0) * HD;
+        const T* __restrict__ Kb = (const T*)p.K + (bh * p.Tp + tok0) * HD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int r = t * 32 + l31; r = r < last ? r : last;
+            kf[t] = *(const V8*)(Kb + (long)r * HD + h * 8);
+            qf[t] = *(const V8*)(Qb + (long)r * HD + h * 8);
+        }
+    };
+    V8 kf[4], qf[4];
+    int head = wave;
+    if (head < p.heads) load_qk(head, kf, qf);
+    // ---- stage V^T of the window (all heads): thread -> (row, 8-byte piece), consecutive threads = consecutive pieces of a row
+    {
+        const int ppr = nkeys >> 2, total = C * ppr;                 // pieces per row (keys are a multiple of 4)
+        const T* __restrict__ Vw = (const T*)p.VT + (long)b * C * (long)p.Tp + tok0;
+        for (int i = tid; i < total; i += 256) {
+            const int row = i / ppr, pc = i - row * ppr;
+            *(V4*)(vs + (size_t)row * VLD + 4 * pc) = *(const V4*)(Vw + (long)row * p.Tp + 4 * pc);
+        }
+    }
+    __syncthreads();
+
+    while (head < p.heads) {
+        const int nh = head + 4;
+        V8 kn[4], qn[4];
+        if (nh < p.heads) load_qk(nh, kn, qn);                      // the next head's Q / K while this one computes
+        const T* vrow = vs + (size_t)(head * HD + (l31 & 15)) * VLD;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            if (qt >= nqt) break;                                   // wave-uniform
+            // ---- S^T tile by tile: register 4 b + e of lane (query l31, h) is key 32 kt + 8 b + 4 h + e
+            f32x16 sc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkt) break;
+                f32x16 a;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a[e] = 0.f;
+                a = Mma32<T>::k16(kf[kt], qf[qt], a);
+                if (kt * 32 + 32 > nvalid) {                        // the ragged last tile: keys past the real tokens
+                    asm volatile("; ragged key tile");
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a[e] = kt * 32 + 8 * (e >> 2) + 4 * h + (e & 3) < nvalid ? a[e] : -INFINITY;
+                }
+                sc[kt] = a;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= nkt) break;
+                float lm = max3(sc[kt][0], sc[kt][1], sc[kt][2]);
+#pragma unroll
+                for (int e = 3; e < 15; e += 2) lm = max3(lm, sc[kt][e], sc[kt][e + 1]);
+                mx = max3(mx, lm, sc[kt][15]);
+            }
+            mx = xor32_max(mx);
+            // ---- P = exp2(S - max) packed per 16-key chunk as the B operand; O^T = V^T P^T with V^T fragments out of LDS. Rows 16-31
+            // of the operand are not channels: row 16 is all ones (the softmax denominator comes out of the same MFMAs), the rest zero
+            f32x16 o;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c >= nch) break;
+                V8 pf, vf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = from_f32<T>(__builtin_amdgcn_exp2f(sc[c >> 1][8 * (c & 1) + e] - mx));
+                if (l31 >= 16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vf[e] = from_f32<T>(l31 == 16 ? 1.f : 0.f);
+                } else {
+                    // runs of 4 keys; a run past the end is clamped to the last run (finite values; its P is exactly 0)
+                    int k0 = 16 * c + 4 * h, k1 = k0 + 8;
+                    k0 = k0 + 4 <= nkeys ? k0 : nkeys - 4; k1 = k1 + 4 <= nkeys ? k1 : nkeys - 4;
+                    const V4 lo = *(const V4*)(vrow + k0), hi = *(const V4*)(vrow + k1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                }
+                o = Mma32<T>::k16(vf, pf, o);
+            }
+            // ---- normalise; register 4 b + e of lane (query, h) is channel 8 b + 4 h + e, the ones row is channel 16 = (b 2, h 0, e 0)
+            const auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8]), __float_as_uint(o[8]), false, false);
+            const float inv = 1.f / (h == 0 ? o[8] : __uint_as_float(rr[0]));
+            V4 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = from_f32<T>(o[e] * inv); hi[e] = from_f32<T>(o[4 + e] * inv); }
+            const u32x2 lu = __builtin_bit_cast(u32x2, lo), hu = __builtin_bit_cast(u32x2, hi);
+            // lower lanes keep lo (channels 0-3) and take the upper lanes' lo (4-7); upper lanes take the lower lanes' hi (8-11) and keep hi
+            const auto s0 = __builtin_amdgcn_permlane32_swap(lu[0], hu[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(lu[1], hu[1], false, false);
+            const u32x4v st = {s0[0], s1[0], s0[1], s1[1]};
+            const int q = qt * 32 + l31;
+            if (q < nkeys) *(u32x4v*)(os + (size_t)q * OLD + head * HD + 8 * h) = st;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { kf[t] = kn[t]; qf[t] = qn[t]; }
+        head = nh;
+    }
+    __syncthreads();
+    // ---- the window's rows, 16 bytes per lane, consecutive lanes = consecutive pieces (one contiguous run when ldo = C)
+    {
+        const int cpr = C >> 3, total = nkeys * cpr;
+        T* __restrict__ out = (T*)p.out + ((long)b * p.Tp + tok0) * p.ldo;
+        for (int i = tid; i < total; i += 256) {
+            const int row = i / cpr, c8 = i - row * cpr;
+            *(u32x4v*)(out + (long)row * p.ldo + 8 * c8) = *(const u32x4v*)(os + (size_t)row * OLD + 8 * c8);
+        }
+    }
+}
+
+template <typename T>
+int launch_wtile(const lwdetr_attn_desc& p, hipStream_t st) {
+    const int C = p.heads * 16, VLD = ((p.keys_per_seq + 7) & ~7) + 8;
+    const size_t lds = ((size_t)C * VLD + (size_t)p.keys_per_seq * (C + 8)) * sizeof(T);
+    static signed char state[16] = {};          // per device: 0 = not asked yet, 1 = granted, -1 = refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_UNSUPPORTED;
+    if (state[dev] == 0)
+        state[dev] = hipFuncSetAttribute((const void*)attn_wtile_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? 1 : -1;
+    if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
+    const double nseq = (double)p.B * p.seqs_per_img;
+    const double flops = 4.0 * nseq * p.heads * (double)p.keys_per_seq * p.keys_per_seq * 16;
+    const double bytes = 4.0 * nseq * p.heads * p.keys_per_seq * 16 * sizeof(T);
+    const int kid = p.kind == 0 ? KID_ATTN_WINDOW : (p.kind == 1 ? KID_ATTN_GLOBAL : KID_ATTN_DECODER);
+    ProfScope ps(kid, flops, bytes, st);
+    hipLaunchKernelGGL((attn_wtile_kernel<T>), dim3((unsigned)(p.B * p.seqs_per_img)), dim3(256), lds, st, p);
     return lwdetr_check_launch();
 }
 
@@ -901,6 +1096,20 @@ int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
 
 template <typename T, int HD>
 int launch(const lwdetr_attn_desc& p, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && HD == 16) {
+        // window tiles through LDS (round 5): one workgroup per (image, window), all heads. LWDETR_ATTN_WTILE: 0 = never, 1 = whenever
+        // legal (tests), default = when the grid has at least one workgroup per two CUs (below that the per-head waves of
+        // attn_kernel spread a few windows wider)
+        const char* wenv = getenv("LWDETR_ATTN_WTILE");
+        const int wmode = wenv ? atoi(wenv) : 2;
+        const int C = p.heads * 16, VLD = ((p.keys_per_seq + 7) & ~7) + 8;
+        const size_t lds = ((size_t)C * VLD + (size_t)p.keys_per_seq * (C + 8)) * sizeof(T);
+        if (wmode != 0 && p.keys_per_seq <= 128 && p.sub_stride >= p.keys_per_seq && p.ldo % 8 == 0 && ((size_t)p.out & 15) == 0 &&
+            ((size_t)p.VT & 7) == 0 && p.seq_tok_stride % 4 == 0 && lds <= 128 * 1024 && (wmode == 1 || (long)p.B * p.seqs_per_img >= 128)) {
+            const int rc = launch_wtile<T>(p, st);
+            if (rc != LWDETR_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if constexpr (sizeof(T) == 2 && (HD == 16 || HD == 32)) {
         // one wave per (sequence, head): sequences of at most 128 keys whose pad rows sit behind the real tokens.
         // Measured (tools/attn_bench.py, us per launch, attn_kernel | this kernel): hd 32, 100-key windows, medium B = 64 bf16

@@ -984,17 +984,8 @@ extern "C" int lwdetr_debug_big_timing(unsigned long long* out) {
 // epilogue (256 KB through LDS, 128 KB of stores) with the CU's matrix pipes idle; with a second, independent workgroup on the CU
 // one tile's epilogue / prologue runs beside the other's k-loop (profiles/r5a_*).
 template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN, int BM = 256, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const lwdetr_gemm_desc d, const int stagger) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const lwdetr_gemm_desc d) {
     static_assert(sizeof(T) == 2, "16-bit types only");
-    // Start skew (tuning, LWDETR_GEMM_BIG_STAGGER = groups * 1000 + microseconds-tenths per group): all tiles of a launch take the
-    // same time, so the workgroups of a round reach their prologue (HBM reads) and their epilogue (128 KB of stores each) together
-    // and those phases run at the chip's HBM rate with idle matrix pipes. Delaying the first round's workgroups group by group
-    // spreads the phases for the rest of the launch (later workgroups start whenever a CU falls free).
-    if (stagger > 0 && blockIdx.x < 256) {
-        const int groups = stagger / 1000, tenths = stagger % 1000;
-        const int g = (blockIdx.x >> 3) % groups;                  // CU-level index inside the XCD (block b runs on XCD b % 8)
-        for (int i = 0; i < g * tenths; ++i) __builtin_amdgcn_s_sleep(3);      // 3 x 64 clocks = 0.09 us at 2.1 GHz: ~0.1 us per round
-    }
     static_assert((NW == 8 && BM == 256) || (NW == 4 && BM == 128), "8 waves x 256 rows or 4 waves x 128 rows");
     constexpr int EPC = 8;
     constexpr int WGN = BN == 256 ? 4 : 2, WGM = NW / WGN;        // wave grid: 2 x 4 (BN 256) or 4 x 2 (BN 192 / 128); NW = 4: 1 x 4 / 2 x 2
@@ -1267,8 +1258,7 @@ int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
     static_assert(NW == 8 || lds <= 80 * 1024, "two workgroups per CU");
     const long nwg = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    const char* sg_env = getenv("LWDETR_GEMM_BIG_STAGGER");
-    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE, BM, NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, d, sg_env ? atoi(sg_env) : 0);
+    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE, BM, NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, d);
     return lwdetr_check_launch();
 }
 
@@ -1279,12 +1269,15 @@ int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
 // LWDETR_GEMM_BIG / lwdetr_gemm_tuning(): 0 = never, 1 = default thresholds, 2 = whenever legal (tests), 32 / 64 = whenever
 // legal with that stage depth (tuning).
 int g_big_mode = -1;
-// Shapes on which the 4-wave / 128-row form (two workgroups per CU) measured faster than the 8-wave 256-row one
-// (profiles/r5a_gemm_big_2wg.txt): placeholder until measured - short k-loops, where prologue + epilogue are a large share of a tile.
+// Shapes on which the 4-wave / 128-row form (two workgroups per CU) measured faster than the 8-wave 256-row one: none by a margin
+// that shows at model level (profiles/r5a_gemm_big_2wg_and_start_skew.txt: xlarge K = 768 shapes -3 .. +3 %, K = 3072 -23 %, C = 384
+// shapes -2 .. +6 %; xlarge 960x960 786 -> 750 img/s, large +-0, medium +1.4 %). A 128 x 256 tile pulls 1.5x the bytes per MFMA into
+// the CU and needs 32-deep stages (a barrier and six DMA issues per 16 MFMAs of a wave) to fit twice: what the second workgroup hides of
+// the other's prologue and epilogue the slower k-loop gives back. The form stays selectable (LWDETR_GEMM_BIG_2WG=2, tests).
 template <int AMODE>
 bool big_2wg_pays(const lwdetr_gemm_desc& d, int bn) {
-    (void)bn;
-    return d.K <= 1024 && AMODE == LWDETR_A_PLAIN;
+    (void)d; (void)bn;
+    return false;
 }
 template <typename T, int AMODE>
 int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {

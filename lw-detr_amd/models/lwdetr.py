@@ -12,6 +12,7 @@ from torch import nn
 
 from .. import _native
 from ..engine import ForwardPlan, PackedWeights
+from ..plan_cache import PlanCache
 from .modules import (MLP, Backbone, Joiner, PositionEmbeddingSine, Transformer, focal_prior_bias)
 from .nested import NestedTensor, nested_tensor_from_tensor_list
 
@@ -55,13 +56,13 @@ class LWDETR(nn.Module):
         self._export = False
         self._args = copy.copy(args)
         self._packed = None      # PackedWeights for the current (device, dtype, parameter versions)
-        self._plans = {}         # (B, H, W) -> ForwardPlan
+        self._plans = PlanCache()         # (B, H, W, slot) -> ForwardPlan, bounded (plan_cache.py)
         self._tok_tensors = None
         self._side_streams = {}  # device -> side streams of the launch chains (a stream belongs to one device)
 
     # ---- cache invalidation: any change of device / dtype / parameter values drops the packed weights
     def invalidate_cache(self):
-        self._packed, self._plans, self._tok_tensors = None, {}, None
+        self._packed, self._plans, self._tok_tensors = None, PlanCache(), None
         self._side_streams = {}
 
     def _apply(self, fn, *a, **k):

@@ -35,6 +35,12 @@ class PlanCache:
     def keys(self):
         return list(self._plans)
 
+    def values(self):
+        return list(self._plans.values())
+
+    def __getitem__(self, key):          # no LRU update: inspection by tests / tools
+        return self._plans[key]
+
     def clear(self):
         self._plans.clear()
 

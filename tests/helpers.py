@@ -102,33 +102,55 @@ def oracle_batch(size, batch, res, img_seed, seed=0, chunk=2, forced_topk=None):
     return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
 
 
-def oracle_lowp(size, n, res, img_seed, dtype, forced_topk, seed=0, threads=16):
-    """The reference arithmetic IN A 16-BIT DTYPE on the CPU (VERDICT r2 item 3a): oracle/lwdetr_torch.py with every parameter
-    and the input cast to ``dtype`` - each torch op then rounds its result to that dtype, as the reference does under
-    ``model.half()`` / bfloat16 - for the first ``n`` images of synth_images(., res, res, img_seed), with the two-stage
-    selection forced. The deformable sampling core runs in float32 on the 16-bit value / location / weight tensors (CPU
-    grid_sample returns NaN in half precision; the reference's own path casts there too, models/transformer.py:356).
-    Returns final + encoder logits / boxes as float32 numpy arrays: their distance to the fp32 oracle is what 16-bit
-    arithmetic itself costs on this network - the yardstick for the HIP path's 16-bit error."""
+def _oracle_lowp_chunk(job):
+    size, idx, res, img_seed, dtype_name, forced, seed, threads = job
+    import torch as _t
+    _t.set_num_threads(threads)
     import lwdetr_amd
     from lwdetr_amd.synth import synth_images, synth_state_dict
     from oracle import lwdetr_torch as O
-    torch.set_num_threads(threads)
+    dtype = getattr(_t, dtype_name)
     cfg = lwdetr_amd.get_args(size)
     model, _, _ = lwdetr_amd.build_model(cfg)
     sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in synth_state_dict(model.state_dict(), seed=seed).items()}
-    x = synth_images(n, res, res, seed=img_seed).to(dtype)
+    x = synth_images(max(idx) + 1, res, res, seed=img_seed)[list(idx)].to(dtype)      # counter-based generator: image i is the same in any batch
     core = O.msda_core
     O.msda_core = lambda value, shapes, loc, aw: core(value.float(), shapes, loc.float(), aw.float()).to(value.dtype)
     try:
-        with torch.no_grad():
-            out = O.forward(sd, cfg, x, forced_topk=torch.from_numpy(np.ascontiguousarray(forced_topk[:n])))
+        with _t.no_grad():
+            out = O.forward(sd, cfg, x, forced_topk=_t.from_numpy(np.ascontiguousarray(forced)))
     finally:
         O.msda_core = core
     f = lambda t: t.float().numpy()
     return {"pred_logits": f(out["pred_logits"]), "pred_boxes": f(out["pred_boxes"]),
             "enc_logits": f(out["enc_outputs"]["pred_logits"]), "enc_boxes": f(out["enc_outputs"]["pred_boxes"]),
-            "aux_logits": [f(a["pred_logits"]) for a in out["aux_outputs"]], "aux_boxes": [f(a["pred_boxes"]) for a in out["aux_outputs"]]}
+            "aux_logits": np.stack([f(a["pred_logits"]) for a in out["aux_outputs"]], 1),
+            "aux_boxes": np.stack([f(a["pred_boxes"]) for a in out["aux_outputs"]], 1)}
+
+
+def oracle_lowp(size, n, res, img_seed, dtype, forced_topk, seed=0, threads=16, idx=None, chunk=2):
+    """The reference arithmetic IN A 16-BIT DTYPE on the CPU (VERDICT r2 item 3a): oracle/lwdetr_torch.py with every parameter
+    and the input cast to ``dtype`` - each torch op then rounds its result to that dtype, as the reference does under
+    ``model.half()`` / bfloat16 - for images ``idx`` (default: the first ``n``) of synth_images(., res, res, img_seed), with the
+    two-stage selection forced (``forced_topk`` is indexed with the same ``idx``). The deformable sampling core runs in float32 on
+    the 16-bit value / location / weight tensors (CPU grid_sample returns NaN in half precision; the reference's own path casts
+    there too, models/transformer.py:356). Images are independent: chunks of ``chunk`` images run in worker processes side by side.
+    Returns final + encoder (+ auxiliary) logits / boxes as float32 numpy arrays in the order of ``idx``: their distance to the
+    fp32 oracle is what 16-bit arithmetic itself costs on this network - the yardstick for the HIP path's 16-bit error."""
+    import multiprocessing as mp
+    idx = list(range(n)) if idx is None else [int(i) for i in idx]
+    cores = len(os.sched_getaffinity(0))
+    groups = [idx[i:i + chunk] for i in range(0, len(idx), chunk)]
+    procs = max(1, min(len(groups), cores // 8))
+    th = max(1, min(threads, cores // procs))
+    name = str(dtype).split(".")[-1]
+    jobs = [(size, g, res, img_seed, name, np.ascontiguousarray(forced_topk[g]), seed, th) for g in groups]
+    if procs == 1:
+        parts = [_oracle_lowp_chunk(j) for j in jobs]
+    else:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            parts = pool.map(_oracle_lowp_chunk, jobs)
+    return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
 
 
 def box_iou_xyxy(a, b):

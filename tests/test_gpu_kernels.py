@@ -314,6 +314,7 @@ def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkey
     qs = (q.float() * K.attention_scale(hd)).to(dtype)
     vt = v.transpose(2, 3).contiguous()
     outs = []
+    monkeypatch.setenv("LWDETR_ATTN_WTILE", "0")
     for win in ("1", "0"):
         monkeypatch.setenv("LWDETR_ATTN_WIN", win)
         out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())
@@ -328,6 +329,30 @@ def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkey
     e_old = ((outs[1] - ref)[:, :, valid]).abs().max().item()
     assert e_new < {torch.float16: 6e-3, torch.bfloat16: 4e-2}[dtype] and e_new < 1.5 * e_old + 1e-4, (e_new, e_old)
     assert torch.isfinite(outs[0]).all()              # pad rows are written too (finite)
+    if hd == 16:
+        # round 5: the window-tile kernel (one workgroup per (image, window), V^T and the output tile through LDS) runs the same MFMA
+        # sequence per (window, head) as the one-wave kernel: bit-identical, pad rows included
+        monkeypatch.setenv("LWDETR_ATTN_WTILE", "1")
+        out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())
+        K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd, seqs_per_img=spi, seq_tok_stride=twp,
+                 keys_per_seq=twp, sub_stride=twp, sub_len=tw, kind=0)()
+        ow = out.reshape(b, tp, heads, hd).permute(0, 2, 1, 3).float()
+        assert torch.equal(ow, outs[0]), (ow - outs[0]).abs().max().item()
+        # ... also into a wider output row (ldo > C) and with 12 heads (three per wave)
+        b2, h2 = 3, 12
+        q2, k2, v2 = (_rand(b2, h2, tp, hd, dtype=dtype, seed=s_) for s_ in (11, 12, 13))
+        vt2 = v2.transpose(2, 3).contiguous()
+        res = []
+        for wt in ("1", "0"):
+            monkeypatch.setenv("LWDETR_ATTN_WTILE", wt)
+            o2 = torch.full((b2 * tp, h2 * hd + 64), 7.0, dtype=dtype, device=_dev())
+            K.AttnOp(q2, k2, vt2, o2, B=b2, heads=h2, hd=hd, Tp=tp, ldo=h2 * hd + 64, seqs_per_img=spi, seq_tok_stride=twp,
+                     keys_per_seq=twp, sub_stride=twp, sub_len=tw, kind=0)()
+            res.append(o2)
+        assert bool((res[0][:, h2 * hd:] == 7.0).all())                       # nothing outside the rows' C channels
+        val = ((torch.arange(tp, device=_dev()) % twp) < tw).repeat(b2)
+        d2 = (res[0][:, :h2 * hd].float() - res[1][:, :h2 * hd].float())[val].abs().max().item()
+        assert d2 < {torch.float16: 2e-3, torch.bfloat16: 2e-2}[dtype], d2
 
 
 @pytest.fixture

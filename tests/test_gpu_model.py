@@ -137,6 +137,52 @@ def test_low_precision_teacher_forced(name, dtype, tol_mem, tol_logit, tol_box, 
     assert torch.isfinite(free["pred_logits"].float()).all()
 
 
+# Bounds = those of test_low_precision_teacher_forced (<= 2x measured at the golden batch sizes); the replicated batch must meet them too.
+@pytest.mark.parametrize("name,dtype,reps,tol_logit,tol_box", [("small_640", torch.float16, 8, 0.044, 0.0036),
+                                                                ("tiny_640", torch.float16, 16, 0.044, 0.0036),
+                                                                ("medium_640", torch.bfloat16, 16, 0.26, 0.02),
+                                                                ("large_640", torch.float16, 16, 0.083, 0.0074)])
+def test_golden_images_through_the_benchmarked_16bit_plan(name, dtype, reps, tol_logit, tol_box):
+    """the fused 16-bit kernels that carry the benchmark (stem, block kernel, encoder / row chains, fused FFN)
+    only run from ~8 images up, so the golden tests at their own batch sizes (1-2 images) go through a DIFFERENT launch plan.
+    Here the golden images are replicated to a batch of 16 - the rows / launch plan of one launch chain of BASELINE config 2 - and
+    EVERY replica is compared with the reference-produced golden (teacher-forced selection) within the 16-bit bound of the
+    golden-batch test: ties the benchmarked kernels to a fixture the unmodified reference produced, not only to the restatement."""
+    from lwdetr_amd import kernels as K
+    g = load_golden(name)
+    size, images, mask = case_batch(name)
+    b0 = images.shape[0]
+    model, _ = _model(size, golden_state_dict(g), dtype)
+    x = images.repeat(reps, 1, 1, 1).to(DEV)                    # replica r of image i is row r * b0 + i
+    forced = torch.from_numpy(g["topk_idx"]).repeat(reps, 1).to(DEV)
+    out = model(x, _forced_topk=forced)
+    plan = next(iter(model._plans.values()))
+    names = [type(op).__name__ for op in plan.ops_backbone]
+    assert plan.stem_op is not None and "VitBlockOp" in names and plan.use_chain, names      # the benchmarked launch plan
+    assert any(isinstance(op, K.EncChainOp) for op in plan.ops_enc)
+    if plan.d == 256:                                           # the decoder's row chains are in the plan of the d = 256 models only
+        assert any(isinstance(op, K.RowChainOp) for op in plan.ops_dec)
+    worst = {}
+    for r in range(reps):
+        sl = slice(r * b0, (r + 1) * b0)
+        rep = {"pred_logits": out["pred_logits"][sl], "pred_boxes": out["pred_boxes"][sl],
+               "enc_outputs": {"pred_logits": out["enc_outputs"]["pred_logits"][sl], "pred_boxes": out["enc_outputs"]["pred_boxes"][sl]},
+               "aux_outputs": [{"pred_logits": a["pred_logits"][sl], "pred_boxes": a["pred_boxes"][sl]} for a in out["aux_outputs"]]}
+        d = _diffs(rep, g)
+        for k_, v in d.items():
+            worst[k_] = max(worst.get(k_, 0.0), v)
+        assert max(d["pred_logits"], d["enc_logits"]) < tol_logit, (r, d)
+        assert max(d["pred_boxes"], d["enc_boxes"]) < tol_box, (r, d)
+        assert max(v for k_, v in d.items() if k_.startswith("aux") and k_.endswith("logits")) < 1.5 * tol_logit, (r, d)
+    # images are independent: every replica of an image sees the same arithmetic whatever tile / workgroup its rows land in
+    first = out["pred_logits"][:b0]
+    spread = max((out["pred_logits"][r * b0:(r + 1) * b0].float() - first.float()).abs().max().item() for r in range(1, reps))
+    worst["replica_spread_logits"] = spread
+    assert spread <= tol_logit / 4, spread
+    with open(os.path.join(ROOT, "gpurun_out", f"parity_replicated_{str(dtype).split('.')[-1]}_{name}_x{reps}.json"), "w") as f:
+        json.dump(worst, f)
+
+
 @pytest.mark.parametrize("name,dtype,tol_logit,tol_box", [("small_padded", torch.float16, 0.05, 0.005), ("large_padded", torch.float16, 0.09, 0.008),
                                                           ("small_padded", torch.bfloat16, 0.4, 0.04)])
 def test_low_precision_padded_batches_through_the_row_chains(name, dtype, tol_logit, tol_box, monkeypatch):

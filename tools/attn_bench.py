@@ -22,8 +22,10 @@ SHAPES = {  # name: (B, heads, hd, twp, tw, dtype)
     "small_b16_f16_win": (16, 12, 16, 100, 100, "float16"),
     "large_b32_f16_win": (32, 12, 32, 100, 100, "float16"),
 }
-VARIANTS = [("attn_kernel", {"LWDETR_ATTN_LDS": "0", "LWDETR_ATTN_WIN": "0", "LWDETR_ATTN_SHORT": "0"}),
-            ("attn_kernel, loads up front short", {"LWDETR_ATTN_LDS": "0", "LWDETR_ATTN_WIN": "0"}), ("one wave / window win", {"LWDETR_ATTN_WIN": "1"}),
+VARIANTS = [("attn_kernel", {"LWDETR_ATTN_LDS": "0", "LWDETR_ATTN_WIN": "0", "LWDETR_ATTN_SHORT": "0", "LWDETR_ATTN_WTILE": "0"}),
+            ("attn_kernel, loads up front short", {"LWDETR_ATTN_LDS": "0", "LWDETR_ATTN_WIN": "0", "LWDETR_ATTN_WTILE": "0"}),
+            ("one wave / window win", {"LWDETR_ATTN_WIN": "1", "LWDETR_ATTN_WTILE": "0"}),
+            ("window tile through LDS wtile", {"LWDETR_ATTN_WTILE": "1"}),
             ("lds 1x8", {"LWDETR_ATTN_LDS_CFG": "108", "LWDETR_ATTN_WIN": "0"}),
             ("lds 1x10", {"LWDETR_ATTN_LDS_CFG": "110"}), ("lds 2x4", {"LWDETR_ATTN_LDS_CFG": "204"}),
             ("lds 2x5", {"LWDETR_ATTN_LDS_CFG": "205"}), ("lds 2x8", {"LWDETR_ATTN_LDS_CFG": "208"}),
