@@ -1097,15 +1097,20 @@ int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
 template <typename T, int HD>
 int launch(const lwdetr_attn_desc& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && HD == 16) {
-        // window tiles through LDS (round 5): one workgroup per (image, window), all heads. LWDETR_ATTN_WTILE: 0 = never, 1 = whenever
-        // legal (tests), default = when the grid has at least one workgroup per two CUs (below that the per-head waves of
-        // attn_kernel spread a few windows wider)
+        // window tiles through LDS (round 5): one workgroup per (image, window), all heads. Built for the north star's "LDS-staged window
+        // tiles" and measured SLOWER than the per-head waves below (tools/attn_bench.py, hd 16, 100-key windows, us per launch incl. ~5 us
+        // of launch overhead: B = 32 attn_kernel 33.7 | one wave per (window, head) 38.6 | this kernel 61.1; B = 16 19.3 | 25.1 | 34.9;
+        // config 2 13.4-13.5 k -> 13.0 k img/s), and the ablations of the one-wave kernel say why staging cannot pay here: with EVERY
+        // load and store removed it still runs 29.6 of its 38.6 us, without the exponentials 37.5 - window attention at hd 16 is bound by
+        // the dependent MFMA -> max -> exp -> MFMA chain of a (window, head) at 2-3 waves per SIMD, not by its 79 MB of traffic
+        // (profiles/r5c_window_attention_hd16.txt). Off unless asked for: LWDETR_ATTN_WTILE=1 (tests keep it bit-identical to the
+        // one-wave kernel).
         const char* wenv = getenv("LWDETR_ATTN_WTILE");
-        const int wmode = wenv ? atoi(wenv) : 2;
+        const int wmode = wenv ? atoi(wenv) : 0;
         const int C = p.heads * 16, VLD = ((p.keys_per_seq + 7) & ~7) + 8;
         const size_t lds = ((size_t)C * VLD + (size_t)p.keys_per_seq * (C + 8)) * sizeof(T);
         if (wmode != 0 && p.keys_per_seq <= 128 && p.sub_stride >= p.keys_per_seq && p.ldo % 8 == 0 && ((size_t)p.out & 15) == 0 &&
-            ((size_t)p.VT & 7) == 0 && p.seq_tok_stride % 4 == 0 && lds <= 128 * 1024 && (wmode == 1 || (long)p.B * p.seqs_per_img >= 128)) {
+            ((size_t)p.VT & 7) == 0 && p.seq_tok_stride % 4 == 0 && lds <= 128 * 1024) {
             const int rc = launch_wtile<T>(p, st);
             if (rc != LWDETR_ERR_UNSUPPORTED) return rc;
         }
