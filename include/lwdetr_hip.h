@@ -92,6 +92,17 @@ typedef struct {           /* one column segment [n_begin, n_end) of the output 
     lwdetr_tok_layout in_tok, out_tok;   /* TOKMAP / DECONV2x2: row decode / encode layouts */
     long out_batch_stride; /* TOKMAP / DECONV2x2: elements between images in out (0 = dense) */
     long out_row_offset;   /* TOKMAP / DECONV2x2: first row inside an image (level offset into `memory`) */
+    /* LayerNorm folded into the GEMM (round 5; `nn.LayerNorm` in front of a Linear, models/backbone/vit.py:199, :217): with W' = W diag(g),
+       b' = b + W beta packed by the host, LN(x) W^T + b = rstd_m (x_m . W'_n - mean_m colsum_n) + b'_n - the GEMM reads the RAW rows and the
+       epilogue applies the row statistics: acc <- (acc - mean * ln_colsum[n]) * rstd before bias / activation. */
+    const float* ln_stats; /* optional (2, M) f32, planar: ln_stats[m] = mean, ln_stats[M + m] = rstd of A row m (lwdetr_row_stats); NULL = plain GEMM */
+    const float* ln_colsum;/* with ln_stats: f32 sum over k of W[n][k] as stored (16-bit rounded), indexed by n - n_begin, padded like bias */
+    float* rowstat_out;    /* optional PRODUCER side of the same fold: per 64-column slot s = n / 64 and row m, (count, mean, M2) of the ROUNDED
+                              outputs this launch writes - rowstat_out[(s * M + m) * 3 ..]; a column tile wider than 64 reports in its first slot
+                              and writes count 0 to the others. lwdetr_row_stats_finish merges the slots of a row (pairwise mean / M2 update) into
+                              (mean, rstd): the next LayerNorm's statistics without another pass over the rows. Contract (else
+                              LWDETR_ERR_UNSUPPORTED): LINEAR mode, no rowmask, M % 64 == 0, n_begin and n_end multiples of 256, 16-byte aligned
+                              rows (ldo, ldres, ld2 multiples of 8 elements). */
 } lwdetr_gemm_seg;
 
 typedef struct {
@@ -110,6 +121,13 @@ typedef struct {
 } lwdetr_gemm_desc;
 
 int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
+/* Row statistics of x (M, C) for the LayerNorm-folded GEMM: stats[m] = mean, stats[M + m] = 1 / sqrt(var + eps) (planar - interleaved pairs made
+ * hipcc broadcast the high half of a register pair into packed-f32 epilogue arithmetic, the instruction form tools/check_isa.py refuses),
+ * two-pass f32 on the stored values -
+ * the arithmetic of lwdetr_layernorm without its output pass (half its HBM traffic). C % 8 == 0 (16-bit) / C % 4 == 0 (f32). */
+int lwdetr_row_stats(const void* x, long ldx, long M, int C, float eps, float* stats, int dtype, void* hip_stream);
+/* (mean, rstd) per row from the (count, mean, M2) slots a GEMM wrote through lwdetr_gemm_seg.rowstat_out (nslots = C / 64). */
+int lwdetr_row_stats_finish(const float* rowstat, int nslots, long M, int C, float eps, float* stats, void* hip_stream);
 /* Kernel selection override for tests / tuning (process-wide): big_mode -1 = default (environment LWDETR_GEMM_BIG, else
  * shape thresholds), 0 = never use the 256-row large-tile kernel, 2 = use it whenever the shape is legal for it,
  * 32 / 64 = as 2 with that stage depth. Results do not depend on it beyond f32 summation order. */

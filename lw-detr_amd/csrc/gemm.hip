@@ -103,6 +103,9 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { gv[e] = g0[e]; gv[4 + e] = g1[e]; }
                 }
+                // LayerNorm folded into the GEMM (ln_stats): acc <- (acc - mean_m * colsum_n) * rstd_m before the bias. The fast path is
+                // instantiated with and without it (a run-time test kept 16 more registers live in every GEMM: spills in the 256 x 256 kernel)
+                const float* __restrict__ lnst = sg.ln_stats;
                 const long coff = col_offset(sg, nl);
                 const int act = sg.act;
                 const float scale = sg.scale;
@@ -112,23 +115,33 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                 // masks and alignment in every sweep, which serialises the sweeps behind each other's memory latency
                 // (measured on the 256 x 256 tile kernel: 9-12 us of epilogue per tile).
                 constexpr int ITS = 64 / RSTEP;
-                const bool fast = 64 % RSTEP == 0 && mbase + 64 <= d.M && !sg.rowmask && !out2 && (n_end - n0) % 8 == 0 &&
+                const bool fast = 64 % RSTEP == 0 && mbase + 64 <= d.M && !sg.rowmask && (n_end - n0) % 8 == 0 &&
                                   (sg.mode == LWDETR_OUT_LINEAR || sg.mode == LWDETR_OUT_HEADS) && sg.ldo % 8 == 0 &&
                                   ((size_t)out & 15) == 0 && (sg.mode == LWDETR_OUT_LINEAR || sg.p1 % 8 == 0) && sg.n_begin % 8 == 0 &&
-                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0));
+                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0)) &&
+                                  (!out2 || (sg.ld2 % 8 == 0 && ((size_t)out2 & 15) == 0));      // round 5: the tap copy no longer leaves the fast path
                 if (fast) {
                     constexpr int G = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
-                    auto finish_all = [&](auto act_tag) {
+                    auto finish_all = [&](auto act_tag, auto ln_tag) {
                         constexpr int ACT = decltype(act_tag)::value;
+                        constexpr bool LN = decltype(ln_tag)::value;
+                        float cs[LN ? 8 : 1];
+                        if constexpr (LN) {
+                            const f32x4 c0 = *(const f32x4*)(sg.ln_colsum + nl), c1 = *(const f32x4*)(sg.ln_colsum + nl + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { cs[e] = c0[e]; cs[4 + e] = c1[e]; }
+                        }
 #pragma unroll 1
                         for (int it0 = 0; it0 < ITS; it0 += G) {
                             f32x4 a0[G], a1[G];
                             V8 rv[G];
                             long ro[G];
+                            float lmean[LN ? G : 1], lrstd[LN ? G : 1];
 #pragma unroll
                             for (int g = 0; g < G; ++g) {
                                 const int row = tid / CPRW + (it0 + g) * RSTEP;
                                 const long m = mbase + row;
+                                if constexpr (LN) { lmean[g] = lnst[m]; lrstd[g] = lnst[(long)d.M + m]; }
                                 if (sg.mode == LWDETR_OUT_LINEAR) ro[g] = m * sg.ldo;
                                 else { const int b = (int)(m / sg.p0), t = (int)(m - (long)b * sg.p0); ro[g] = ((long)b * sg.p2 * sg.p0 + t) * sg.p1; }
                                 a0[g] = *(const f32x4*)(stage + row * SLD + col);
@@ -145,7 +158,14 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                             for (int g = 0; g < G; ++g) {
                                 float x[8];
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { x[e] = a0[g][e] + bv[e]; x[4 + e] = a1[g][e] + bv[4 + e]; }
+                                for (int e = 0; e < 4; ++e) {
+                                    if constexpr (LN) {
+                                        x[e] = fmaf(fmaf(-lmean[g], cs[e], a0[g][e]), lrstd[g], bv[e]);
+                                        x[4 + e] = fmaf(fmaf(-lmean[g], cs[4 + e], a1[g][e]), lrstd[g], bv[4 + e]);
+                                    } else {
+                                        x[e] = a0[g][e] + bv[e]; x[4 + e] = a1[g][e] + bv[4 + e];
+                                    }
+                                }
                                 if (ACT != ACT_NONE) {
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) x[e] = act_apply<T>(x[e], ACT);
@@ -160,14 +180,44 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(x[e]);
                                 *(V8*)(out + ro[g] + coff) = o;
+                                const long mrow = mbase + tid / CPRW + (it0 + g) * RSTEP;
+                                if (out2) *(V8*)(out2 + mrow * sg.ld2 + nl) = o;
+                                if constexpr ((CPRW & (CPRW - 1)) == 0 && CPRW <= 32) {
+                                    if (sg.rowstat_out) {
+                                        // producer side of the folded LayerNorm: (count, mean, M2) of this tile's BN rounded outputs of the row -
+                                        // the CPRW lanes of a row are neighbours inside one wave (two-pass: mean first, then squared deviations)
+                                        float v[8], sum = 0.f;
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) { v[e] = to_f32<T>(o[e]); sum += v[e]; }
+#pragma unroll
+                                        for (int msk = 1; msk < CPRW; msk <<= 1) sum += __shfl_xor(sum, msk);
+                                        const float mt = sum * (1.f / BN);
+                                        float m2 = 0.f;
+#pragma unroll
+                                        for (int e = 0; e < 8; ++e) { const float dv = v[e] - mt; m2 = fmaf(dv, dv, m2); }
+#pragma unroll
+                                        for (int msk = 1; msk < CPRW; msk <<= 1) m2 += __shfl_xor(m2, msk);
+                                        if (tid % CPRW == 0) {
+                                            float* rp = sg.rowstat_out + ((long)(n / 64) * d.M + mrow) * 3;
+                                            rp[0] = (float)BN; rp[1] = mt; rp[2] = m2;
+#pragma unroll
+                                            for (int j = 1; j < BN / 64; ++j) rp[(long)j * d.M * 3] = 0.f;
+                                        }
+                                    }
+                                }
                             }
                         }
                     };
-                    if (act == ACT_NONE) finish_all(std::integral_constant<int, ACT_NONE>{});
-                    else if (act == ACT_GELU) finish_all(std::integral_constant<int, ACT_GELU>{});
-                    else if (act == ACT_SILU) finish_all(std::integral_constant<int, ACT_SILU>{});
-                    else finish_all(std::integral_constant<int, ACT_RELU>{});
-                    return;
+                    if (lnst) {         // LayerNorm in front of a Linear: no activation (QKV) or GELU (fc1); anything else takes the general loop
+                        if (act == ACT_NONE) { finish_all(std::integral_constant<int, ACT_NONE>{}, std::true_type{}); return; }
+                        if (act == ACT_GELU) { finish_all(std::integral_constant<int, ACT_GELU>{}, std::true_type{}); return; }
+                    } else {
+                        if (act == ACT_NONE) finish_all(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
+                        else if (act == ACT_GELU) finish_all(std::integral_constant<int, ACT_GELU>{}, std::false_type{});
+                        else if (act == ACT_SILU) finish_all(std::integral_constant<int, ACT_SILU>{}, std::false_type{});
+                        else finish_all(std::integral_constant<int, ACT_RELU>{}, std::false_type{});
+                        return;
+                    }
                 }
 #pragma unroll
                 for (int it = 0; it < (64 + RSTEP - 1) / RSTEP; ++it) {
@@ -186,6 +236,11 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                         const f32x4 a1 = *(const f32x4*)(stage + row * SLD + col + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { x[e] = keep_acc ? a0[e] : 0.f; x[4 + e] = keep_acc ? a1[e] : 0.f; }
+                    }
+                    if (lnst) {
+                        const float mean = lnst[m], rstd = lnst[(long)d.M + m];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = keep_acc ? fmaf(-mean, sg.ln_colsum[nl + e], x[e]) * rstd : 0.f;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] += bv[e];
@@ -229,6 +284,11 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                     const bool al = (((size_t)obase | ((size_t)sg.p0 * sizeof(T))) & (4 * sizeof(T) - 1)) == 0;
                     const int act = sg.act;
                     const float scale = sg.scale;
+                    float lm[4] = {0.f, 0.f, 0.f, 0.f}, lr[4] = {1.f, 1.f, 1.f, 1.f};     // LayerNorm folded into the GEMM: this thread's 4 rows
+                    if (sg.ln_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (e < cnt) { lm[e] = sg.ln_stats[m + e]; lr[e] = sg.ln_stats[(long)d.M + m + e]; }
+                    }
 #pragma unroll 4
                     for (int coln = tid / RPC; coln < BN; coln += NTHR / RPC) {
                         const int n = n0 + coln;
@@ -236,9 +296,10 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                         const int nl = n - sg.n_begin;
                         const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
                         const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                        const float csn = sg.ln_stats ? sg.ln_colsum[nl] : 0.f;
                         float x[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, act) * scale;
+                        for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(fmaf(fmaf(-lm[e], csn, a0[e]), lr[e], bias), act) * scale;
                         store_run<T, 4>(obase + (long)nl * sg.p0, x, cnt, al);
                     }
                 }
@@ -252,9 +313,14 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                     const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
                     const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
                     const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                    const float csn = sg.ln_stats ? sg.ln_colsum[nl] : 0.f;
                     float x[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, sg.act) * sg.scale;
+                    for (int e = 0; e < 4; ++e) {
+                        float mean = 0.f, rstd = 1.f;
+                        if (sg.ln_stats && e < cnt) { mean = sg.ln_stats[m + e]; rstd = sg.ln_stats[(long)d.M + m + e]; }
+                        x[e] = act_apply<T>(fmaf(fmaf(-mean, csn, a0[e]), rstd, bias), sg.act) * sg.scale;
+                    }
                     const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
                     T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
                     store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
@@ -1473,6 +1539,12 @@ extern "C" int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_st
             (g.p0 <= 0 || g.p1 <= 0 || g.p2 <= 0 || g.p1 % 4 != 0 || g.p0 % 4 != 0)) return LWDETR_ERR_BAD_ARG;
         if (g.mode == LWDETR_OUT_DECONV2x2 && (g.p0 <= 0 || g.p0 % 4 != 0)) return LWDETR_ERR_BAD_ARG;
         if (g.mode < 0 || g.mode > LWDETR_OUT_DECONV2x2) return LWDETR_ERR_BAD_ARG;
+        if ((g.ln_stats != nullptr) != (g.ln_colsum != nullptr)) return LWDETR_ERR_BAD_ARG;
+        if (g.rowstat_out && (g.mode != LWDETR_OUT_LINEAR || g.rowmask || d.M % 64 != 0 || g.n_begin % 256 != 0 || g.n_end % 256 != 0 || g.n_end > d.N ||
+                              g.ldo % 8 != 0 || ((size_t)g.out & 15) != 0 || (g.res && (g.ldres % 8 != 0 || ((size_t)g.res & 15) != 0)) ||
+                              (g.out2 && (g.ld2 % 8 != 0 || ((size_t)g.out2 & 15) != 0)) || dtype == DT_F32))
+            return LWDETR_ERR_UNSUPPORTED;
+        if (g.ln_stats && (d.a_mode != LWDETR_A_PLAIN || d.A2)) return LWDETR_ERR_BAD_ARG;      // row statistics of the plain A rows
     }
     if (d.seg[d.nseg - 1].n_end < d.N) return LWDETR_ERR_BAD_ARG;
     if (d.a_mode == LWDETR_A_PLAIN && (d.lda % epc != 0)) return LWDETR_ERR_BAD_ARG;

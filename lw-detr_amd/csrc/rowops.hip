@@ -152,7 +152,104 @@ int launch_ln(const void* x, long ldx, const float* gamma, const float* beta, vo
     return lwdetr_check_launch();
 }
 
+// Row statistics only (round 5): the first two passes of layernorm_kernel - (mean, rstd) of every row for the LayerNorm-folded GEMM
+// epilogue (gemm.hip: ln_stats) - without the normalised copy of x that lwdetr_layernorm writes and the next GEMM reads back.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, long ldx, long M, int C, float eps, float* __restrict__ stats) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    typedef T VC __attribute__((ext_vector_type(EPC)));
+    const int lane16 = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= M) return;
+    const int nchunks = C / EPC;
+    const T* xr = x + row * ldx;
+    float v[NCH][EPC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane16 + 16 * i;
+        if (c < nchunks) {
+            const VC t = *(const VC*)(xr + c * EPC);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { v[i][e] = to_f32<T>(t[e]); sum += v[i][e]; }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane16 + 16 * i;
+        if (c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { const float dlt = v[i][e] - mean; var += dlt * dlt; }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) var += __shfl_xor(var, o);
+    if (lane16 == 0) { stats[row] = mean; stats[M + row] = 1.f / sqrtf(var / (float)C + eps); }
+}
+template <typename T>
+int launch_row_stats(const void* x, long ldx, long M, int C, float eps, float* stats, hipStream_t st) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    if (C % EPC != 0 || C / EPC > 16 * LN_MAX_CHUNKS || ldx % EPC != 0) return LWDETR_ERR_UNSUPPORTED;
+    const long blocks = (M + 15) / 16;
+    ProfScope ps(KID_LAYERNORM, 0.0, 1.0 * M * C * sizeof(T), st);
+    const int nch = (C / EPC + 15) / 16;
+#define RS_LAUNCH(N) hipLaunchKernelGGL((row_stats_kernel<T, N>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, ldx, M, C, eps, stats)
+    if (nch <= 2) RS_LAUNCH(2);
+    else if (nch <= 3) RS_LAUNCH(3);
+    else if (nch <= 4) RS_LAUNCH(4);
+    else if (nch <= 6) RS_LAUNCH(6);
+    else if (nch <= 8) RS_LAUNCH(8);
+    else if (nch <= 12) RS_LAUNCH(12);
+    else RS_LAUNCH(16);
+#undef RS_LAUNCH
+    return lwdetr_check_launch();
+}
+
 }  // namespace
+
+extern "C" int lwdetr_row_stats(const void* x, long ldx, long M, int C, float eps, float* stats, int dtype, void* hip_stream) {
+    if (!x || !stats || M < 0 || C <= 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    switch (dtype) {
+        case DT_F32: return launch_row_stats<float>(x, ldx, M, C, eps, stats, st);
+        case DT_F16: return launch_row_stats<f16>(x, ldx, M, C, eps, stats, st);
+        case DT_BF16: return launch_row_stats<bf16>(x, ldx, M, C, eps, stats, st);
+        default: return LWDETR_ERR_UNSUPPORTED;
+    }
+}
+
+// (count, mean, M2) slots of a row -> (mean, rstd): pairwise update (Chan et al.), one thread per row
+__global__ __launch_bounds__(256) void row_stats_finish_kernel(const float* __restrict__ rs, int nslots, long M, int C, float eps, float* __restrict__ stats) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < nslots; ++s) {
+        const float* p = rs + ((long)s * M + m) * 3;
+        const float cnt = p[0];
+        if (cnt > 0.f) {
+            const float mt = p[1], dlt = mt - mean, tot = n + cnt;
+            mean += dlt * cnt / tot;
+            m2 += p[2] + dlt * dlt * n * cnt / tot;
+            n = tot;
+        }
+    }
+    stats[m] = mean;
+    stats[M + m] = 1.f / sqrtf(m2 / (float)C + eps);
+}
+
+extern "C" int lwdetr_row_stats_finish(const float* rowstat, int nslots, long M, int C, float eps, float* stats, void* hip_stream) {
+    if (!rowstat || !stats || nslots <= 0 || M < 0 || C <= 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ProfScope ps(KID_LAYERNORM, 0.0, 12.0 * nslots * M + 8.0 * M, st);
+    hipLaunchKernelGGL(row_stats_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, rowstat, nslots, M, C, eps, stats);
+    return lwdetr_check_launch();
+}
 
 extern "C" int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* out, long ldo,
                                 long M, int C, float eps, long rows_per_batch, long out_batch_rows, long out_row_offset,

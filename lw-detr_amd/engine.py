@@ -205,6 +205,20 @@ class ForwardPlan:
                                                                            self.Hp, self.Wp, self.Twp))
         qscale = K.attention_scale(hd)
         fused = K.mlp_fused_supported(C, self.T, rows)
+        # LayerNorm folded into the following GEMM on the unfused path (16-bit, many rows: the C = 768 model; LWDETR_LN_FOLD=0|1 forces it)
+        lf_env = os.environ.get("LWDETR_LN_FOLD")
+        ln_fold = (not fused) and self.T != torch.float32 and (lf_env == "1" or (lf_env is None and rows >= 12800))
+        ln_stats = torch.empty(2, rows, dtype=torch.float32, device=self.dev) if ln_fold else None
+        self.ln_fold = ln_fold
+        # The statistics can also come out of the epilogue of the GEMM that PRODUCES the rows (patch embedding, attention projection, fc2:
+        # seg(rowstat_out=...), merged per row by lwdetr_row_stats_finish) - built, tested, and measured SLOWER than the pass over the rows:
+        # the two in-wave reductions per row cost the producing launches +25 us each (proj 102 -> 130 us, fc2 288 -> 313 us at xlarge 960x960
+        # B = 16) where lwdetr_row_stats costs 19 us; xlarge 759-763 img/s with the pass, 747-751 with the epilogue statistics, 743-747 without
+        # the fold (profiles/r5d_layernorm_fold_xlarge.txt). LWDETR_LN_FOLD_STATS=1 selects the epilogue form.
+        ln_prod = ln_fold and rows % 64 == 0 and C % 256 == 0 and os.environ.get("LWDETR_LN_FOLD_STATS", "0") == "1"
+        rowstat = torch.zeros((C // 64) * rows * 3, dtype=torch.float32, device=self.dev) if ln_prod else None
+        self.ln_prod = ln_prod
+        stats_op = (lambda: K.RowStatsFinishOp(rowstat, ln_stats, rows, C, 1e-6)) if ln_prod else (lambda: K.RowStatsOp(self.x, ln_stats, rows, C, 1e-6))
         blk0_fused = fused and K.vit_block_supported(C, self.T, hd, rows) and rows % Tp == 0 and Tp % 8 == 0
         # round 4: patch embedding + position embedding + block 0's norm1 / QKV as ONE launch at the batch sizes of the block kernel
         self.stem_op = self.patch_op = None
@@ -221,7 +235,7 @@ class ForwardPlan:
             wpe = pw.w(pre + ".patch_embed.proj.weight", lambda t: t.reshape(t.shape[0], -1))
             dummy_img = z(1, 8)
             ops.append(GemmOp(dummy_img, wpe, rows, C, 768, [
-                seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp)],
+                seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp, rowstat_out=rowstat)],
                 a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
             self.patch_op = ops[-1]
         for i in range(self.depth):
@@ -235,6 +249,19 @@ class ForwardPlan:
                     pw.sd[blk + ".attn.qkv.weight"], pw.sd[blk + ".attn.q_bias"], pw.sd[blk + ".attn.v_bias"],
                     pw.sd[blk + ".norm1.weight"], pw.sd[blk + ".norm1.bias"], self.T))
                 ops.append(K.VitQkvOp(self.x, sq, vq, rows, C, 1e-6, q=q, k=k, vt=vt, qscale=qscale, heads=heads, hd=hd, Tp=Tp))
+            elif (i == 0 or not fused) and ln_fold:
+                # round 5 (the unfused C = 768 path): norm1 folded into the QKV GEMM - row statistics only (half the LayerNorm's traffic),
+                # the GEMM reads the raw rows, its epilogue applies (acc - mean colsum) rstd + b' (kernels.fold_layernorm)
+                wq_, cs_, bq_ = pw.custom_multi(blk + ".qkv.lnfold", lambda blk=blk: K.fold_layernorm(
+                    pw.sd[blk + ".attn.qkv.weight"], torch.cat([pw.sd[blk + ".attn.q_bias"].detach().float(), torch.zeros(C, device=self.dev),
+                                                                pw.sd[blk + ".attn.v_bias"].detach().float()]),
+                    pw.sd[blk + ".norm1.weight"], pw.sd[blk + ".norm1.bias"], self.T))
+                ops.append(stats_op())
+                ops.append(GemmOp(self.x, wq_, rows, 3 * C, C, [
+                    seg(q, 0, C, mode=OUT_HEADS, bias=bq_[:C], scale=qscale, p0=Tp, p1=hd, p2=heads, ln_stats=ln_stats, ln_colsum=cs_[:C]),
+                    seg(k, C, 2 * C, mode=OUT_HEADS, bias=bq_[C:2 * C], p0=Tp, p1=hd, p2=heads, ln_stats=ln_stats, ln_colsum=cs_[C:2 * C]),
+                    seg(vt, 2 * C, 3 * C, mode=OUT_HEADS_T, bias=bq_[2 * C:], p0=Tp, p1=hd, p2=heads, ln_stats=ln_stats, ln_colsum=cs_[2 * C:])],
+                    keep=(wq_, cs_, bq_)))
             elif i == 0 or not fused:
                 # norm1 + QKV as separate launches (blocks > 0 get them chained into the previous block's MLP kernel)
                 ops.append(LayerNormOp(self.x, pw.f(blk + ".norm1.weight"), pw.f(blk + ".norm1.bias"), xn, rows, C, 1e-6))
@@ -252,7 +279,7 @@ class ForwardPlan:
             if not fused:
                 ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
-                        res=self.x, ldres=C)]))
+                        res=self.x, ldres=C, rowstat_out=rowstat)]))
             tap_out = None
             if i in self.taps:
                 j = self.taps.index(i)
@@ -287,12 +314,19 @@ class ForwardPlan:
                                         wp=pw.w(blk + ".attn.proj.weight"), bp=pw.f(blk + ".attn.proj.bias"),
                                         gamma1=pw.f(blk + ".gamma_1"), eps_next=1e-6, **nxt))
             else:
-                ops.append(LayerNormOp(self.x, pw.f(blk + ".norm2.weight"), pw.f(blk + ".norm2.bias"), xn, rows, C, 1e-6))
-                ops.append(GemmOp(xn, pw.w(blk + ".mlp.fc1.weight"), rows, 4 * C, C, [
-                    seg(hid, 0, 4 * C, ldo=4 * C, bias=pw.f(blk + ".mlp.fc1.bias"), act=ACT_GELU)]))
+                if ln_fold:        # norm2 folded into fc1 (see norm1 above)
+                    w1_, cs1_, b1_ = pw.custom_multi(blk + ".fc1.lnfold", lambda blk=blk: K.fold_layernorm(
+                        pw.sd[blk + ".mlp.fc1.weight"], pw.sd[blk + ".mlp.fc1.bias"], pw.sd[blk + ".norm2.weight"], pw.sd[blk + ".norm2.bias"], self.T))
+                    ops.append(stats_op())
+                    ops.append(GemmOp(self.x, w1_, rows, 4 * C, C, [
+                        seg(hid, 0, 4 * C, ldo=4 * C, bias=b1_, act=ACT_GELU, ln_stats=ln_stats, ln_colsum=cs1_)], keep=(w1_, cs1_, b1_)))
+                else:
+                    ops.append(LayerNormOp(self.x, pw.f(blk + ".norm2.weight"), pw.f(blk + ".norm2.bias"), xn, rows, C, 1e-6))
+                    ops.append(GemmOp(xn, pw.w(blk + ".mlp.fc1.weight"), rows, 4 * C, C, [
+                        seg(hid, 0, 4 * C, ldo=4 * C, bias=pw.f(blk + ".mlp.fc1.bias"), act=ACT_GELU)]))
                 ops.append(GemmOp(hid, pw.w(blk + ".mlp.fc2.weight"), rows, C, 4 * C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".mlp.fc2.bias"), gamma=pw.f(blk + ".gamma_2"), res=self.x,
-                        ldres=C, out2=tap_out, ld2=ntap * C)], keep=(tap_out,)))
+                        ldres=C, out2=tap_out, ld2=ntap * C, rowstat_out=rowstat if i + 1 < self.depth else None)], keep=(tap_out,)))
 
     def _vit_block_ok(self, blk):
         """lwdetr_vit_block divides by the LayerScale vectors: blocks with (near-)zero entries stay on lwdetr_mlp_fused."""

@@ -38,11 +38,20 @@ def tok_layout(winmajor=False, hp=0, wp=0, twp=0) -> TokLayout:
 
 def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE, scale=1.0, gamma=None, res=None,
         ldres=0, res_mod=0, out2=None, ld2=0, rowmask=None, rowmask_after=False, p0=0, p1=0, p2=0, in_tok=None, out_tok=None,
-        out_batch_stride=0, out_row_offset=0) -> GemmSeg:
-    """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h)."""
+        out_batch_stride=0, out_row_offset=0, ln_stats=None, ln_colsum=None, rowstat_out=None) -> GemmSeg:
+    """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h). ln_stats (M, 2) f32 + ln_colsum (n) f32:
+    LayerNorm folded into the GEMM (fold_layernorm packs the weights; RowStatsOp produces the planar (2, M) statistics)."""
     s = GemmSeg()
     bias, gamma = _pad8(bias, n_end - n_begin, 0.0), _pad8(gamma, n_end - n_begin, 1.0)
-    s._keep = (bias, gamma)           # padded copies must outlive the launch
+    assert (ln_stats is None) == (ln_colsum is None)
+    if ln_stats is not None:
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_colsum.dtype == torch.float32
+        ln_colsum = _pad8(ln_colsum, n_end - n_begin, 0.0)
+        s.ln_stats, s.ln_colsum = _ptr(ln_stats), _ptr(ln_colsum)
+    if rowstat_out is not None:
+        assert rowstat_out.dtype == torch.float32 and rowstat_out.is_contiguous()
+        s.rowstat_out = _ptr(rowstat_out)
+    s._keep = (bias, gamma, ln_stats, ln_colsum, rowstat_out)           # padded copies must outlive the launch
     s.out, s.out2, s.res = _ptr(out), _ptr(out2), _ptr(res)
     s.bias, s.gamma, s.rowmask = _ptr(bias), _ptr(gamma), _ptr(rowmask)
     assert rowmask is None or rowmask.dtype == torch.uint8
@@ -119,6 +128,48 @@ class LayerNormOp:
         rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
         if rc:
             _nat.check(rc, "layernorm")
+
+
+class RowStatsOp:
+    """stats (2, M) f32, planar: stats[0, m] = mean, stats[1, m] = rstd of row m of x (M, C): the statistics half of a LayerNorm, for a GEMM
+    with the LayerNorm folded in."""
+
+    def __init__(self, x, stats, M, C_, eps, *, ldx=None):
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= 2 * M
+        self.args = (_ptr(x), ldx if ldx is not None else C_, M, C_, float(eps), _ptr(stats), _nat.dtype_code(x.dtype))
+        self._keep = (x, stats)
+        self._fn = _nat.lib().lwdetr_row_stats
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "row_stats")
+
+
+class RowStatsFinishOp:
+    """stats (2, M) planar = (mean, rstd) from the (count, mean, M2) slots the producing GEMM wrote (seg(rowstat_out=...)): no pass over the rows."""
+
+    def __init__(self, rowstat, stats, M, C_, eps):
+        assert rowstat.dtype == torch.float32 and stats.dtype == torch.float32 and C_ % 64 == 0 and rowstat.numel() >= (C_ // 64) * M * 3
+        self.args = (_ptr(rowstat), C_ // 64, M, C_, float(eps), _ptr(stats))
+        self._keep = (rowstat, stats)
+        self._fn = _nat.lib().lwdetr_row_stats_finish
+
+    def __call__(self, stream=None):
+        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
+        if rc:
+            _nat.check(rc, "row_stats_finish")
+
+
+def fold_layernorm(w, b, ln_w, ln_b, dtype):
+    """LayerNorm (affine ln_w, ln_b) in front of Linear(w, b), folded for lwdetr_gemm's ln_stats epilogue:
+    LN(x) w^T + b = rstd (x . w'_n - mean colsum_n) + b'_n with w' = w diag(ln_w) rounded to the compute dtype, colsum_n = sum_k w'_nk of the
+    ROUNDED weights in f32 (what the MFMA contraction of a constant row yields), b' = b + w ln_b in f32. Returns (w', colsum, b')."""
+    wf = w.detach().float()
+    wq = (wf * ln_w.detach().float()[None, :]).to(dtype).contiguous()
+    colsum = wq.float().sum(1).contiguous()
+    bq = (wf @ ln_b.detach().float() + (b.detach().float() if b is not None else 0.0)).contiguous()
+    return wq, colsum, bq
 
 
 class LayerNormChainOp:

@@ -406,6 +406,97 @@ def test_gemm_large_tile_kernel_head_layouts(dtype, hd, wg2, big_gemm, monkeypat
     _check_qkv_layouts(dtype, hd, 1, 1000)          # ragged last row tile (1000 = 7 x 128 + 104)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,c,mode", [(1000, 768, -1), (4160, 768, 2), (2048, 384, 2), (4099, 768, 128), (12800, 768, -1), (300, 256, -1)])
+def test_gemm_with_layernorm_folded_in(dtype, m, c, mode):
+    """Round 5: LayerNorm folded into the following GEMM (lwdetr_gemm_seg.ln_stats / ln_colsum + lwdetr_row_stats + kernels.fold_layernorm)
+    vs the torch fp32 formulation LN(x) W^T + b and vs the two launches it replaces (lwdetr_layernorm + GEMM): QKV-shaped (HEADS / HEADS /
+    HEADS_T segments, scaled q) and fc1-shaped (GELU) outputs, rows with a large common offset (mean >> std: the cancellation case), the
+    64 x 64 ring kernel (mode -1 at these sizes), the 256-row large-tile kernel (2) and its 4-wave form (128), ragged M."""
+    from lwdetr_amd import _native, kernels as K
+    heads = 12 if c % 12 == 0 else 8
+    hd = c // heads
+    x = (_rand(m, c, dtype=torch.float32, seed=1) * (0.5 + 2 * _rand(m, 1, dtype=torch.float32, seed=2).abs()) + 8 * _rand(m, 1, dtype=torch.float32, seed=3)).to(dtype)
+    lw, lb = _rand(c, seed=4) * 0.2 + 1, _rand(c, seed=5) * 0.1
+    wqkv = _rand(3 * c, c, scale=c ** -0.5, seed=6)
+    bqkv = torch.cat([_rand(c, seed=7) * 0.1, torch.zeros(c, device=_dev()), _rand(c, seed=8) * 0.1])
+    w1, b1 = _rand(4 * c, c, scale=c ** -0.5, seed=9), _rand(4 * c, seed=10) * 0.1
+    stats = torch.empty(2, m, device=_dev())                # planar: row 0 = mean, row 1 = rstd
+    K.RowStatsOp(x, stats, m, c, 1e-6)()
+    xf = x.float()
+    assert (stats[0] - xf.mean(1)).abs().max().item() < 1e-4 * (1 + xf.abs().max().item())
+    rs = (xf.var(1, unbiased=False) + 1e-6).rsqrt()
+    assert ((stats[1] - rs).abs() / rs).max().item() < 1e-4
+    ln = F.layer_norm(xf, (c,), lw, lb, 1e-6)
+    tp = m
+    sp = lambda t_: t_.reshape(1, tp, heads, hd).permute(0, 2, 1, 3)
+    _native.lib().lwdetr_gemm_tuning(mode)
+    try:
+        # QKV
+        wq_, cs_, bq_ = K.fold_layernorm(wqkv, bqkv, lw, lb, dtype)
+        if m % 4 == 0:
+            q = torch.zeros(1, heads, tp, hd, dtype=dtype, device=_dev()); k = torch.zeros_like(q)
+            vt = torch.zeros(1, heads, hd, tp, dtype=dtype, device=_dev())
+            K.GemmOp(x, wq_, m, 3 * c, c, [
+                K.seg(q, 0, c, mode=K.OUT_HEADS, bias=bq_[:c], scale=0.37, p0=tp, p1=hd, p2=heads, ln_stats=stats, ln_colsum=cs_[:c]),
+                K.seg(k, c, 2 * c, mode=K.OUT_HEADS, bias=bq_[c:2 * c], p0=tp, p1=hd, p2=heads, ln_stats=stats, ln_colsum=cs_[c:2 * c]),
+                K.seg(vt, 2 * c, 3 * c, mode=K.OUT_HEADS_T, bias=bq_[2 * c:], p0=tp, p1=hd, p2=heads, ln_stats=stats, ln_colsum=cs_[2 * c:])])()
+            y = ln @ wqkv.t() + bqkv
+            tol = TOL[dtype] * 2
+            assert _relerr(q, sp(y[:, :c]) * 0.37) < tol and _relerr(k, sp(y[:, c:2 * c])) < tol
+            assert _relerr(vt, sp(y[:, 2 * c:]).transpose(2, 3)) < tol
+        # fc1 + GELU, against the fp32 formulation and against the two launches it replaces
+        w1_, cs1_, b1_ = K.fold_layernorm(w1, b1, lw, lb, dtype)
+        hid = torch.zeros(m, 4 * c, dtype=dtype, device=_dev())
+        K.GemmOp(x, w1_, m, 4 * c, c, [K.seg(hid, 0, 4 * c, ldo=4 * c, bias=b1_, act=K.ACT_GELU, ln_stats=stats, ln_colsum=cs1_)])()
+        ref = F.gelu(ln @ w1.t() + b1)
+        two = K.linear(K.layernorm(x, lw, lb, 1e-6), w1.to(dtype), b1, act=K.ACT_GELU)
+        e_new, e_old = _relerr(hid, ref), _relerr(two, ref)
+        assert e_new < TOL[dtype] * 2 and e_new < 1.5 * e_old + 1e-4, (e_new, e_old)
+    finally:
+        _native.lib().lwdetr_gemm_tuning(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,n,k,mode", [(1024, 768, 768, -1), (4160, 768, 3072, 2), (4096, 768, 768, 128), (2048, 256, 512, -1), (12800, 768, 768, 2)])
+def test_gemm_row_statistics_from_the_epilogue(dtype, m, n, k, mode):
+    """Round 5, producer side of the folded LayerNorm: a GEMM with seg(rowstat_out=...) reports (count, mean, M2) of the rounded outputs of
+    every row per column tile, lwdetr_row_stats_finish merges them - vs mean / rstd of the output rows computed by torch, and vs
+    lwdetr_row_stats (a pass over the rows). Residual + LayerScale epilogue with a tap copy (the fc2 launch of a tap block), rows with a
+    large common offset; 64 x 64 ring kernel, 256-row large-tile kernel, its 4-wave form. The contract violations are refused."""
+    from lwdetr_amd import _native, kernels as K
+    x = _rand(m, k, dtype=dtype, seed=1)
+    w = _rand(n, k, dtype=dtype, scale=k ** -0.5, seed=2)
+    bias, gamma = _rand(n, seed=3), _rand(n, seed=4) * 0.3 + 0.5
+    res = (_rand(m, n, dtype=torch.float32, seed=5) * 2 + 6 * _rand(m, 1, dtype=torch.float32, seed=6)).to(dtype)
+    out, tap = torch.empty(m, n, dtype=dtype, device=_dev()), torch.zeros(m, 2 * n, dtype=dtype, device=_dev())
+    rowstat = torch.full(((n // 64) * m * 3,), float("nan"), device=_dev())
+    stats, stats2 = torch.empty(2, m, device=_dev()), torch.empty(2, m, device=_dev())
+    _native.lib().lwdetr_gemm_tuning(mode)
+    try:
+        K.GemmOp(x, w, m, n, k, [K.seg(out, 0, n, ldo=n, bias=bias, gamma=gamma, res=res, ldres=n, out2=tap[:, n:], ld2=2 * n, rowstat_out=rowstat)])()
+    finally:
+        _native.lib().lwdetr_gemm_tuning(-1)
+    K.RowStatsFinishOp(rowstat, stats, m, n, 1e-6)()
+    K.RowStatsOp(out, stats2, m, n, 1e-6)()
+    torch.cuda.synchronize()
+    assert torch.equal(tap[:, n:], out) and tap[:, :n].abs().max().item() == 0
+    ref = res.float() + gamma * (x.float() @ w.float().t() + bias)
+    assert _relerr(out, ref) < TOL[dtype]
+    of = out.float()
+    mean, rstd = of.mean(1), (of.var(1, unbiased=False) + 1e-6).rsqrt()
+    assert torch.isfinite(stats).all()
+    assert (stats[0] - mean).abs().max().item() < 2e-5 * (1 + of.abs().max().item())
+    assert ((stats[1] - rstd).abs() / rstd).max().item() < 1e-4
+    assert (stats - stats2).abs().max().item() < 1e-3 and ((stats[1] - stats2[1]).abs() / stats2[1]).max().item() < 1e-4
+    # contract: ragged M, a segment that is not a multiple of 256 columns, HEADS layout -> refused, nothing silently skipped
+    for bad in (dict(m=m - 8), dict(n=n - 64), dict(mode=K.OUT_HEADS)):
+        mm, nn = bad.get("m", m), bad.get("n", n)
+        kw = dict(mode=K.OUT_HEADS, p0=mm, p1=nn // 4, p2=4) if "mode" in bad else dict(ldo=n)
+        with pytest.raises(_native.NativeError):
+            K.GemmOp(x, w, mm, nn, k, [K.seg(out, 0, nn, rowstat_out=rowstat, **kw)])()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c", [192, 256, 384, 768])
 def test_layernorm(dtype, c):
