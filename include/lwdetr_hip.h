@@ -97,12 +97,13 @@ typedef struct {           /* one column segment [n_begin, n_end) of the output 
        epilogue applies the row statistics: acc <- (acc - mean * ln_colsum[n]) * rstd before bias / activation. */
     const float* ln_stats; /* optional (2, M) f32, planar: ln_stats[m] = mean, ln_stats[M + m] = rstd of A row m (lwdetr_row_stats); NULL = plain GEMM */
     const float* ln_colsum;/* with ln_stats: f32 sum over k of W[n][k] as stored (16-bit rounded), indexed by n - n_begin, padded like bias */
-    float* rowstat_out;    /* optional PRODUCER side of the same fold: per 64-column slot s = n / 64 and row m, (count, mean, M2) of the ROUNDED
-                              outputs this launch writes - rowstat_out[(s * M + m) * 3 ..]; a column tile wider than 64 reports in its first slot
-                              and writes count 0 to the others. lwdetr_row_stats_finish merges the slots of a row (pairwise mean / M2 update) into
-                              (mean, rstd): the next LayerNorm's statistics without another pass over the rows. Contract (else
-                              LWDETR_ERR_UNSUPPORTED): LINEAR mode, no rowmask, M % 64 == 0, n_begin and n_end multiples of 256, 16-byte aligned
-                              rows (ldo, ldres, ld2 multiples of 8 elements). */
+    float* rowstat_out;    /* optional PRODUCER side of the same fold: per 64-column slot s = n / 64 and row m a 16-byte record (count, mean, M2, -)
+                              of the ROUNDED outputs this launch writes - rowstat_out[(s * M + m) * 4 ..]; a column tile wider than 64 reports in
+                              its first slot only, so the buffer must be ZERO-INITIALISED once and belong to ONE producing GEMM (one tile width):
+                              slots it never writes keep count 0. lwdetr_row_stats_finish merges the slots of a row (pairwise mean / M2 update)
+                              into (mean, rstd): the next LayerNorm's statistics without another pass over the rows. Contract (else
+                              LWDETR_ERR_UNSUPPORTED): 16-bit, LINEAR mode, no rowmask, M % 64 == 0, n_begin and n_end multiples of 256, 16-byte
+                              aligned rows (ldo, ldres, ld2 multiples of 8 elements). */
 } lwdetr_gemm_seg;
 
 typedef struct {
@@ -118,6 +119,13 @@ typedef struct {
     int img_h, img_w;
     int nseg;
     lwdetr_gemm_seg seg[3];
+    /* Split-K for few-row GEMMs with a long contraction (round 5): splitk >= 2 asks for that many workgroups per 64 x 64 tile, each over a
+       contiguous range of k-stages; honoured only where the launch takes the 64 x 64 DMA ring kernel (16-bit, no A2), ignored elsewhere.
+       splitk_ws: 16-byte aligned workspace of tiles * splitk * 4352 floats (f32 partial tiles) followed by `tiles` ints (arrival counters),
+       tiles = ceil(M / 64) * ceil(N / 64); the counters must be ZERO before the first launch (every launch leaves them zero), the workspace
+       belongs to one launch at a time. Results do not depend on the arrival order (slabs are summed in slice order). */
+    void* splitk_ws;
+    int splitk;
 } lwdetr_gemm_desc;
 
 int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
@@ -126,7 +134,7 @@ int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
  * two-pass f32 on the stored values -
  * the arithmetic of lwdetr_layernorm without its output pass (half its HBM traffic). C % 8 == 0 (16-bit) / C % 4 == 0 (f32). */
 int lwdetr_row_stats(const void* x, long ldx, long M, int C, float eps, float* stats, int dtype, void* hip_stream);
-/* (mean, rstd) per row from the (count, mean, M2) slots a GEMM wrote through lwdetr_gemm_seg.rowstat_out (nslots = C / 64). */
+/* (mean, rstd) per row, planar (2, M), from the (count, mean, M2, -) records a GEMM wrote through lwdetr_gemm_seg.rowstat_out (nslots = C / 64). */
 int lwdetr_row_stats_finish(const float* rowstat, int nslots, long M, int C, float eps, float* stats, void* hip_stream);
 /* Kernel selection override for tests / tuning (process-wide): big_mode -1 = default (environment LWDETR_GEMM_BIG, else
  * shape thresholds), 0 = never use the 256-row large-tile kernel, 2 = use it whenever the shape is legal for it,

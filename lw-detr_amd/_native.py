@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
                 ("K", C.c_int), ("lda", C.c_long), ("a_mode", C.c_int), ("a_tok", TokLayout),
                 ("conv_cin", C.c_int), ("conv_stride", C.c_int), ("a_col0", C.c_int), ("conv_hout", C.c_int),
                 ("conv_wout", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int), ("nseg", C.c_int),
-                ("seg", GemmSeg * 3)]
+                ("seg", GemmSeg * 3), ("splitk_ws", C.c_void_p), ("splitk", C.c_int)]
 
 
 class AttnDesc(C.Structure):

@@ -714,7 +714,10 @@ static bool lds_path_applies(const lwdetr_attn_desc& p) {
     if (p.keys_per_seq % 8 != 0 && !p.vt_slack) return false;
     // a grid that cannot fill the chip (single image: 7 x 12 workgroups of 256 queries) is faster on attn_kernel's 128-query
     // workgroups: 21.7 vs 27.0 us at B = 1, hd 16, 1600 keys (tools/attn_bench.py small_b1_f16)
-    if (mode != 3 && (long)((p.keys_per_seq + 255) / 256) * p.heads * p.B * p.seqs_per_img < 256) return false;
+    // (round 5: at hd 16 the ring kernel runs 128-query workgroups since round 4 - 156 of them for one image - and wins from there:
+    // single-image p50 0.867 -> 0.857 ms with it on the four global-attention launches, tools/lat_bs1.py, profiles/r5e_*)
+    if (mode != 3 && (p.hd == 16 ? (long)((p.keys_per_seq + 127) / 128) * p.heads * p.B * p.seqs_per_img < 128
+                                 : (long)((p.keys_per_seq + 255) / 256) * p.heads * p.B * p.seqs_per_img < 256)) return false;
     return p.keys_per_seq % 4 == 0 && p.seq_tok_stride % 4 == 0 && p.Tp % 4 == 0 && p.ldo % 8 == 0 &&
            (p.sub_len == p.sub_stride || p.sub_stride >= 64);
 }

@@ -66,6 +66,26 @@ __device__ __forceinline__ void store_run(T* dst, const float* x, int cnt, bool 
     }
 }
 
+// all-reduce (sum) over aligned groups of NL = 8 / 16 / 32 neighbouring lanes on the VALU: xor 1, 2 as quad permutes, then mirrors inside 8 and
+// 16 lanes (every lane of a reduced sub-group already holds its sum, so a mirror pairs the sub-groups exactly as an xor would), then a
+// v_permlane16_swap across the two rows of a 32-lane half
+template <int NL> __device__ __forceinline__ float row_allreduce_sum(float v) {
+    static_assert(NL == 8 || NL == 16 || NL == 32, "8, 16 or 32 lanes");
+    auto dpp_add = [](float x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true);
+        return x + __int_as_float(y);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});        // quad_perm [1, 0, 3, 2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});        // quad_perm [2, 3, 0, 1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});       // row_half_mirror
+    if constexpr (NL >= 16) v = dpp_add(v, std::integral_constant<int, 0x140>{});      // row_mirror
+    if constexpr (NL == 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
+}
+
 // ---- shared epilogue: accumulators -> LDS (f32) -> fused bias / activation / scale / LayerScale / residual / masks ->
 // coalesced 16-byte stores in the destination layout of the tile's column segment.
 // Second half of the epilogue, shared by every GEMM kernel: one pass of 64 tile rows, already staged in LDS as f32
@@ -122,9 +142,10 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                                   (!out2 || (sg.ld2 % 8 == 0 && ((size_t)out2 & 15) == 0));      // round 5: the tap copy no longer leaves the fast path
                 if (fast) {
                     constexpr int G = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
-                    auto finish_all = [&](auto act_tag, auto ln_tag) {
+                    auto finish_all = [&](auto act_tag, auto ln_tag, auto st_tag) {
                         constexpr int ACT = decltype(act_tag)::value;
                         constexpr bool LN = decltype(ln_tag)::value;
+                        constexpr bool ST = decltype(st_tag)::value && (CPRW & (CPRW - 1)) == 0 && CPRW <= 32;      // producer-side row statistics
                         float cs[LN ? 8 : 1];
                         if constexpr (LN) {
                             const f32x4 c0 = *(const f32x4*)(sg.ln_colsum + nl), c1 = *(const f32x4*)(sg.ln_colsum + nl + 4);
@@ -147,11 +168,17 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                                 a0[g] = *(const f32x4*)(stage + row * SLD + col);
                                 a1[g] = *(const f32x4*)(stage + row * SLD + col + 4);
                             }
+                            float pivv[ST ? G : 1];
+#pragma unroll
+                            for (int g = 0; g < (ST ? G : 1); ++g) pivv[g] = 0.f;
                             if (res) {
 #pragma unroll
                                 for (int g = 0; g < G; ++g) {
                                     const long m = mbase + tid / CPRW + (it0 + g) * RSTEP;
                                     rv[g] = *(const V8*)(res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl);
+                                    // pivot of the row statistics (below): the residual's first element of this tile, fetched WITH the residual
+                                    // (a load behind the output stores makes hipcc drain them: vmcnt counts both)
+                                    if constexpr (ST) pivv[g] = to_f32<T>(res[(sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + (n0 - sg.n_begin)]);
                                 }
                             }
 #pragma unroll
@@ -182,40 +209,44 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                                 *(V8*)(out + ro[g] + coff) = o;
                                 const long mrow = mbase + tid / CPRW + (it0 + g) * RSTEP;
                                 if (out2) *(V8*)(out2 + mrow * sg.ld2 + nl) = o;
-                                if constexpr ((CPRW & (CPRW - 1)) == 0 && CPRW <= 32) {
-                                    if (sg.rowstat_out) {
-                                        // producer side of the folded LayerNorm: (count, mean, M2) of this tile's BN rounded outputs of the row -
-                                        // the CPRW lanes of a row are neighbours inside one wave (two-pass: mean first, then squared deviations)
-                                        float v[8], sum = 0.f;
+                                if constexpr (ST) {
+                                    {
+                                        // producer side of the folded LayerNorm: (count, mean, M2) of this tile's BN rounded outputs of the row.
+                                        // One pass: sums of (v - p) and (v - p)^2 around a pivot every lane of the row knows without talking to
+                                        // the others - the residual's first element of this tile (the row's old value there: within a few
+                                        // standard deviations of the new mean, which is all the cancellation in S2 - S1^2 / n needs) - then one
+                                        // all-reduce of the two sums over the row's CPRW lanes on the VALU (DPP butterflies inside 16 lanes,
+                                        // a permlane16 swap across them; the first form used ds_bpermute shuffles and a second pass for the
+                                        // deviations: +25 us per producing launch, profiles/r5d_*)
+                                        const float piv = pivv[g];
+                                        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                                        for (int e = 0; e < 8; ++e) { v[e] = to_f32<T>(o[e]); sum += v[e]; }
-#pragma unroll
-                                        for (int msk = 1; msk < CPRW; msk <<= 1) sum += __shfl_xor(sum, msk);
-                                        const float mt = sum * (1.f / BN);
-                                        float m2 = 0.f;
-#pragma unroll
-                                        for (int e = 0; e < 8; ++e) { const float dv = v[e] - mt; m2 = fmaf(dv, dv, m2); }
-#pragma unroll
-                                        for (int msk = 1; msk < CPRW; msk <<= 1) m2 += __shfl_xor(m2, msk);
-                                        if (tid % CPRW == 0) {
-                                            float* rp = sg.rowstat_out + ((long)(n / 64) * d.M + mrow) * 3;
-                                            rp[0] = (float)BN; rp[1] = mt; rp[2] = m2;
-#pragma unroll
-                                            for (int j = 1; j < BN / 64; ++j) rp[(long)j * d.M * 3] = 0.f;
-                                        }
+                                        for (int e = 0; e < 8; ++e) { const float dv = to_f32<T>(o[e]) - piv; s1 += dv; s2 = fmaf(dv, dv, s2); }
+                                        s1 = row_allreduce_sum<CPRW>(s1); s2 = row_allreduce_sum<CPRW>(s2);
+                                        const float mt = piv + s1 * (1.f / BN), m2 = fmaxf(s2 - s1 * s1 * (1.f / BN), 0.f);
+                                        // ONE 16-byte store per row and tile (the first form wrote six dwords - count / mean / M2 and zero
+                                        // counts for the other slots the tile covers: 7x the store instructions of the epilogue, +25 us per
+                                        // launch). Slots a launch never writes keep the count 0 the host initialised them with: a rowstat
+                                        // buffer belongs to ONE producing GEMM (one column tile width).
+                                        if (tid % CPRW == 0)
+                                            *(f32x4*)(sg.rowstat_out + ((long)(n / 64) * d.M + mrow) * 4) = f32x4{(float)BN, mt, m2, 0.f};
                                     }
                                 }
                             }
                         }
                     };
+                    // instantiated per feature: a run-time test of the rarely used ones keeps their registers live in every GEMM (the 256 x 256
+                    // kernel sits at its 256-register limit: 36 spilled registers with both tests inside one body, none with three bodies)
                     if (lnst) {         // LayerNorm in front of a Linear: no activation (QKV) or GELU (fc1); anything else takes the general loop
-                        if (act == ACT_NONE) { finish_all(std::integral_constant<int, ACT_NONE>{}, std::true_type{}); return; }
-                        if (act == ACT_GELU) { finish_all(std::integral_constant<int, ACT_GELU>{}, std::true_type{}); return; }
+                        if (act == ACT_NONE) { finish_all(std::integral_constant<int, ACT_NONE>{}, std::true_type{}, std::false_type{}); return; }
+                        if (act == ACT_GELU) { finish_all(std::integral_constant<int, ACT_GELU>{}, std::true_type{}, std::false_type{}); return; }
+                    } else if (sg.rowstat_out) {       // producer of a folded LayerNorm's rows: projection / fc2 / patch embedding (no activation)
+                        if (act == ACT_NONE && (CPRW & (CPRW - 1)) == 0 && CPRW <= 32) { finish_all(std::integral_constant<int, ACT_NONE>{}, std::false_type{}, std::true_type{}); return; }
                     } else {
-                        if (act == ACT_NONE) finish_all(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
-                        else if (act == ACT_GELU) finish_all(std::integral_constant<int, ACT_GELU>{}, std::false_type{});
-                        else if (act == ACT_SILU) finish_all(std::integral_constant<int, ACT_SILU>{}, std::false_type{});
-                        else finish_all(std::integral_constant<int, ACT_RELU>{}, std::false_type{});
+                        if (act == ACT_NONE) finish_all(std::integral_constant<int, ACT_NONE>{}, std::false_type{}, std::false_type{});
+                        else if (act == ACT_GELU) finish_all(std::integral_constant<int, ACT_GELU>{}, std::false_type{}, std::false_type{});
+                        else if (act == ACT_SILU) finish_all(std::integral_constant<int, ACT_SILU>{}, std::false_type{}, std::false_type{});
+                        else finish_all(std::integral_constant<int, ACT_RELU>{}, std::false_type{}, std::false_type{});
                         return;
                     }
                 }
@@ -536,8 +567,16 @@ __device__ __forceinline__ void gdma16(const void* src, const void* lds_wave_bas
 
 // KB = k-depth of a stage: 32 (a DMA piece = 16 rows x 64 B) or 64 (8 rows x 128 B: whole cache lines, half the
 // barriers / waits / address updates per byte; slot c of row r lives at slot c ^ ((r >> 1) & (KB / 8 - 1))).
-template <typename T, int BM, int BN, int AMODE, int NST, int KB = 32>
+// SPLITK (round 5; 64 x 64 tiles only): few-row GEMMs with a long contraction (one image: the 3x3 convolutions of the projector, M = 1600,
+// K = 1152 on 50 tiles - 36 dependent DMA -> barrier -> fragment -> MFMA steps, 19 us where the matrix work is < 1 us) run d.splitk
+// workgroups per tile, each over a contiguous range of k-stages. A workgroup stages its partial tile in LDS as usual, writes it to its
+// slab of d.splitk_ws (f32), publishes it (agent-scope release fence, then a relaxed ticket on the tile's counter) and leaves; the one that
+// draws the last ticket acquires, sums ALL slabs of the tile in slice order (its own included, from memory: the f32 sum does not depend on
+// who arrives last - results stay bit-reproducible), resets the counter and runs the epilogue. Slices of a tile are neighbours in the
+// (XCD-remapped) workgroup order, so the slabs are read out of the reducer's own L2.
+template <typename T, int BM, int BN, int AMODE, int NST, int KB = 32, bool SPLITK = false>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d) {
+    static_assert(!SPLITK || (BM == 64 && BN == 64), "split-K: 64 x 64 tiles");
     constexpr int EPC = 8;
     constexpr int SLOTS = KB / EPC, RP = 64 / SLOTS, KC = KB / 32;   // 16-byte slots per row, rows per DMA piece, MFMA k-chunks
     constexpr int A_MY = BM / RP / 4, B_MY = BN / RP / 4;        // DMA pieces (64 slots) per wave and operand
@@ -556,7 +595,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
         const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int nsl = SPLITK ? d.splitk : 1;
+    const int tile = SPLITK ? wg / nsl : wg, slice = SPLITK ? wg - tile * nsl : 0;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const long m0 = (long)tm * BM;
     const int n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -594,14 +635,16 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
         const int n = n0 + RP * (wave + 4 * k) + prow;
         w_src[k] = n < d.N ? W + (long)n * d.K + ccol_of(wave + 4 * k) : nullptr;
     }
-    const int nk = d.K / KB;
+    const int nk_all = d.K / KB;
+    const int kt_lo = SPLITK ? (int)((long)slice * nk_all / nsl) : 0, kt_hi = SPLITK ? (int)((long)(slice + 1) * nk_all / nsl) : nk_all;
+    const int nk = kt_hi - kt_lo;        // this workgroup's k-stages: [kt_lo, kt_hi)
     const T* conv_src[A_MY]; int conv_tap[A_MY];
 #pragma unroll
     for (int k = 0; k < A_MY; ++k) { conv_src[k] = nullptr; conv_tap[k] = -1; }
     auto stage = [&](int kt) {           // always PER_TILE pieces; tiles past the end of K read the zero page
         T* As = smem + (kt % NST) * STAGE;
         T* Bs = As + BM * KB;
-        const int k0 = kt * KB;
+        const int k0 = (kt_lo + kt) * KB;
         const bool live = kt < nk;
 #pragma unroll
         for (int k = 0; k < A_MY; ++k) {
@@ -682,7 +725,49 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const lwdetr_gemm_desc d)
         }
     }
     __syncthreads();            // drains the dummy tail pieces and the last fragment reads before LDS is re-used
-    gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, smem, m0, n0);
+    if constexpr (SPLITK) {
+        // ---- partial tile -> LDS stage (gemm_epilogue's layout for BM = 64) -> slab -> ticket; the last arriver reduces and finishes
+        constexpr int SLD = BN + 4, SLD_T = 64 + 4, SLAB = 64 * 68;         // floats per slab (either orientation)
+        float* stg = (float*)smem;
+        int* flag = (int*)smem + SLAB + 16;                                 // one word of the same LDS array (no second __shared__ object)
+        static_assert((SLAB + 32) * 4 <= LDS_ELEMS * (int)sizeof(T), "stage + flag fit the ring area");
+        {
+            float* sp = col_orient ? stg + (wn * WN + l15) * SLD_T + wm * WM + g * 4 : stg + (wm * WM + l15) * SLD + wn * WN + g * 4;
+            const int fs = col_orient ? 16 * SLD_T : 16, ts = col_orient ? 16 : 16 * SLD;
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int t = 0; t < TT; ++t) *(f32x4*)(sp + f * fs + t * ts) = acc[f][t];
+        }
+        __syncthreads();
+        float* ws = (float*)d.splitk_ws;
+        const long ntiles = (long)gridDim.x / nsl;
+        int* cnt = (int*)(ws + ntiles * nsl * SLAB);
+        float* slab = ws + ((long)tile * nsl + slice) * SLAB;
+        for (int i = tid; i < SLAB / 4; i += 256) ((f32x4*)slab)[i] = ((const f32x4*)stg)[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the write-back is complete before the ticket is drawn (guide G16)
+            *flag = __hip_atomic_fetch_add(cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*flag != nsl - 1) return;                                       // workgroup-uniform: not the last slice of this tile
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        const float* s0 = ws + (long)tile * nsl * SLAB;
+        for (int i = tid; i < SLAB / 4; i += 256) {
+            f32x4 a = ((const f32x4*)s0)[i];
+            for (int s2 = 1; s2 < nsl; ++s2) { const f32x4 b = ((const f32x4*)(s0 + (long)s2 * SLAB))[i]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+            ((f32x4*)stg)[i] = a;
+        }
+        if (tid == 0) __hip_atomic_store(cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch starts from zero
+        __syncthreads();
+        epilogue_finish<T, BN, 256>(d, sg, col_orient, stg, m0, n0);
+    } else {
+        gemm_epilogue<T, BM, BN>(d, sg, col_orient, acc, smem, m0, n0);
+    }
 }
 
 template <typename T> struct Mma32;
@@ -1493,6 +1578,8 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
                 static const char* nst_env = getenv("LWDETR_GEMM_NST");
                 const int nst = nst_env ? atoi(nst_env) : 3;
                 if (nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 2>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+                else if (nst == 3 && d.splitk >= 2 && d.splitk_ws && d.K / 32 >= d.splitk)          // round 5: few rows, long K (see gemm_dma_kernel)
+                    hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3, 32, true>), dim3((unsigned)(nwg * d.splitk)), dim3(256), 0, st, d);
                 else if (nst == 3) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3>), dim3((unsigned)nwg), dim3(256), 0, st, d);
                 else hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             }
@@ -1542,11 +1629,12 @@ extern "C" int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_st
         if ((g.ln_stats != nullptr) != (g.ln_colsum != nullptr)) return LWDETR_ERR_BAD_ARG;
         if (g.rowstat_out && (g.mode != LWDETR_OUT_LINEAR || g.rowmask || d.M % 64 != 0 || g.n_begin % 256 != 0 || g.n_end % 256 != 0 || g.n_end > d.N ||
                               g.ldo % 8 != 0 || ((size_t)g.out & 15) != 0 || (g.res && (g.ldres % 8 != 0 || ((size_t)g.res & 15) != 0)) ||
-                              (g.out2 && (g.ld2 % 8 != 0 || ((size_t)g.out2 & 15) != 0)) || dtype == DT_F32))
+                              (g.out2 && (g.ld2 % 8 != 0 || ((size_t)g.out2 & 15) != 0)) || dtype == DT_F32 || g.act != LWDETR_ACT_NONE))
             return LWDETR_ERR_UNSUPPORTED;
         if (g.ln_stats && (d.a_mode != LWDETR_A_PLAIN || d.A2)) return LWDETR_ERR_BAD_ARG;      // row statistics of the plain A rows
     }
     if (d.seg[d.nseg - 1].n_end < d.N) return LWDETR_ERR_BAD_ARG;
+    if (d.splitk < 0 || d.splitk > 16 || (d.splitk >= 2 && (!d.splitk_ws || ((size_t)d.splitk_ws & 15) != 0))) return LWDETR_ERR_BAD_ARG;
     if (d.a_mode == LWDETR_A_PLAIN && (d.lda % epc != 0)) return LWDETR_ERR_BAD_ARG;
     if (d.a_mode == LWDETR_A_CONV3x3 &&
         (d.conv_cin % BK != 0 || d.K != 9 * d.conv_cin || (d.conv_stride != 1 && d.conv_stride != 2) ||

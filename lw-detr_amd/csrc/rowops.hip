@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void row_stats_finish_kernel(const float* __re
     if (m >= M) return;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int s = 0; s < nslots; ++s) {
-        const float* p = rs + ((long)s * M + m) * 3;
+        const f32x4 p = *(const f32x4*)(rs + ((long)s * M + m) * 4);       // (count, mean, M2, -)
         const float cnt = p[0];
         if (cnt > 0.f) {
             const float mt = p[1], dlt = mt - mean, tot = n + cnt;
@@ -246,7 +246,7 @@ extern "C" int lwdetr_row_stats_finish(const float* rowstat, int nslots, long M,
     if (!rowstat || !stats || nslots <= 0 || M < 0 || C <= 0) return LWDETR_ERR_BAD_ARG;
     if (M == 0) return LWDETR_OK;
     hipStream_t st = (hipStream_t)hip_stream;
-    ProfScope ps(KID_LAYERNORM, 0.0, 12.0 * nslots * M + 8.0 * M, st);
+    ProfScope ps(KID_LAYERNORM, 0.0, 16.0 * nslots * M + 8.0 * M, st);
     hipLaunchKernelGGL(row_stats_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, rowstat, nslots, M, C, eps, stats);
     return lwdetr_check_launch();
 }

@@ -216,9 +216,12 @@ class ForwardPlan:
         # B = 16) where lwdetr_row_stats costs 19 us; xlarge 759-763 img/s with the pass, 747-751 with the epilogue statistics, 743-747 without
         # the fold (profiles/r5d_layernorm_fold_xlarge.txt). LWDETR_LN_FOLD_STATS=1 selects the epilogue form.
         ln_prod = ln_fold and rows % 64 == 0 and C % 256 == 0 and os.environ.get("LWDETR_LN_FOLD_STATS", "0") == "1"
-        rowstat = torch.zeros((C // 64) * rows * 3, dtype=torch.float32, device=self.dev) if ln_prod else None
+        # one zero-initialised record buffer per producing GEMM (patch embedding, projection, fc2: their column tiles differ, and a slot a
+        # launch never writes must keep count 0)
+        rs_new = lambda: torch.zeros((C // 64) * rows * 4, dtype=torch.float32, device=self.dev) if ln_prod else None
+        rs_patch, rs_proj, rs_fc2 = rs_new(), rs_new(), rs_new()
         self.ln_prod = ln_prod
-        stats_op = (lambda: K.RowStatsFinishOp(rowstat, ln_stats, rows, C, 1e-6)) if ln_prod else (lambda: K.RowStatsOp(self.x, ln_stats, rows, C, 1e-6))
+        stats_op = lambda rs: K.RowStatsFinishOp(rs, ln_stats, rows, C, 1e-6) if ln_prod else K.RowStatsOp(self.x, ln_stats, rows, C, 1e-6)
         blk0_fused = fused and K.vit_block_supported(C, self.T, hd, rows) and rows % Tp == 0 and Tp % 8 == 0
         # round 4: patch embedding + position embedding + block 0's norm1 / QKV as ONE launch at the batch sizes of the block kernel
         self.stem_op = self.patch_op = None
@@ -235,7 +238,7 @@ class ForwardPlan:
             wpe = pw.w(pre + ".patch_embed.proj.weight", lambda t: t.reshape(t.shape[0], -1))
             dummy_img = z(1, 8)
             ops.append(GemmOp(dummy_img, wpe, rows, C, 768, [
-                seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp, rowstat_out=rowstat)],
+                seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp, rowstat_out=rs_patch)],
                 a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
             self.patch_op = ops[-1]
         for i in range(self.depth):
@@ -256,7 +259,7 @@ class ForwardPlan:
                     pw.sd[blk + ".attn.qkv.weight"], torch.cat([pw.sd[blk + ".attn.q_bias"].detach().float(), torch.zeros(C, device=self.dev),
                                                                 pw.sd[blk + ".attn.v_bias"].detach().float()]),
                     pw.sd[blk + ".norm1.weight"], pw.sd[blk + ".norm1.bias"], self.T))
-                ops.append(stats_op())
+                ops.append(stats_op(rs_patch if i == 0 else rs_fc2))
                 ops.append(GemmOp(self.x, wq_, rows, 3 * C, C, [
                     seg(q, 0, C, mode=OUT_HEADS, bias=bq_[:C], scale=qscale, p0=Tp, p1=hd, p2=heads, ln_stats=ln_stats, ln_colsum=cs_[:C]),
                     seg(k, C, 2 * C, mode=OUT_HEADS, bias=bq_[C:2 * C], p0=Tp, p1=hd, p2=heads, ln_stats=ln_stats, ln_colsum=cs_[C:2 * C]),
@@ -279,7 +282,7 @@ class ForwardPlan:
             if not fused:
                 ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
-                        res=self.x, ldres=C, rowstat_out=rowstat)]))
+                        res=self.x, ldres=C, rowstat_out=rs_proj)]))
             tap_out = None
             if i in self.taps:
                 j = self.taps.index(i)
@@ -317,7 +320,7 @@ class ForwardPlan:
                 if ln_fold:        # norm2 folded into fc1 (see norm1 above)
                     w1_, cs1_, b1_ = pw.custom_multi(blk + ".fc1.lnfold", lambda blk=blk: K.fold_layernorm(
                         pw.sd[blk + ".mlp.fc1.weight"], pw.sd[blk + ".mlp.fc1.bias"], pw.sd[blk + ".norm2.weight"], pw.sd[blk + ".norm2.bias"], self.T))
-                    ops.append(stats_op())
+                    ops.append(stats_op(rs_proj))
                     ops.append(GemmOp(self.x, w1_, rows, 4 * C, C, [
                         seg(hid, 0, 4 * C, ldo=4 * C, bias=b1_, act=ACT_GELU, ln_stats=ln_stats, ln_colsum=cs1_)], keep=(w1_, cs1_, b1_)))
                 else:
@@ -326,7 +329,7 @@ class ForwardPlan:
                         seg(hid, 0, 4 * C, ldo=4 * C, bias=pw.f(blk + ".mlp.fc1.bias"), act=ACT_GELU)]))
                 ops.append(GemmOp(hid, pw.w(blk + ".mlp.fc2.weight"), rows, C, 4 * C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".mlp.fc2.bias"), gamma=pw.f(blk + ".gamma_2"), res=self.x,
-                        ldres=C, out2=tap_out, ld2=ntap * C, rowstat_out=rowstat if i + 1 < self.depth else None)], keep=(tap_out,)))
+                        ldres=C, out2=tap_out, ld2=ntap * C, rowstat_out=rs_fc2 if i + 1 < self.depth else None)], keep=(tap_out,)))
 
     def _vit_block_ok(self, blk):
         """lwdetr_vit_block divides by the LayerScale vectors: blocks with (near-)zero entries stay on lwdetr_mlp_fused."""

@@ -65,11 +65,31 @@ def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE,
     return s
 
 
+SPLITK_SLAB = 64 * 68          # floats of one partial 64 x 64 tile in the kernel's stage layout (gemm.hip: gemm_dma_kernel SPLITK)
+
+
+def splitk_for(M, N, K, dtype, has_a2=False):
+    """Workgroups per 64 x 64 tile for a few-row GEMM with a long contraction (round 5; the single-image latency path: the 3x3 convolutions
+    of the projector are 36 dependent k-stages on 50 tiles): 16-bit, up to 3200 rows, K >= 512, and only while tiles x splits stay within
+    one round of the chip; at least 8 stages of 32 per slice. LWDETR_GEMM_SPLITK=0 switches it off, n forces n where legal."""
+    env = os.environ.get("LWDETR_GEMM_SPLITK")
+    if dtype not in (torch.float16, torch.bfloat16) or has_a2 or K % 32 != 0:
+        return 1
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if env is not None:
+        n = int(env)
+        return n if (n >= 2 and K // 32 >= n) else 1
+    if M > 3200 or K < 512 or tiles > 128:
+        return 1
+    return max(1, min(4, (K // 32) // 8, 256 // tiles))
+
+
 class GemmOp:
     """out = epilogue(A_view(M,K) @ W(N,K)^T). Keeps references to every tensor it points at."""
 
     def __init__(self, A, W, M, N, K, segs, *, lda=None, A2=None, a_mode=A_PLAIN, a_tok=None, conv_cin=0,
-                 conv_stride=1, a_col0=0, conv_hout=0, conv_wout=0, img_h=0, img_w=0, keep=()):
+                 conv_stride=1, a_col0=0, conv_hout=0, conv_wout=0, img_h=0, img_w=0, keep=(), splitk=None):
+        """splitk: None = automatic (few rows + long contraction: see splitk_for), 0 / 1 = off, n >= 2 = n workgroups per 64 x 64 tile."""
         N_ = N
         assert W.dtype == A.dtype and W.is_contiguous()
         d = GemmDesc()
@@ -84,7 +104,13 @@ class GemmOp:
         for i, s in enumerate(segs):
             d.seg[i] = s
         self.desc, self.dtype = d, _nat.dtype_code(A.dtype)
-        self._keep = (A, A2, W, segs) + tuple(keep)
+        ws = None
+        nsplit = splitk_for(M, N_, K, A.dtype, A2 is not None) if splitk is None else int(splitk)
+        if nsplit >= 2:
+            tiles = ((M + 63) // 64) * ((N_ + 63) // 64)
+            ws = torch.zeros(tiles * nsplit * SPLITK_SLAB + tiles + 4, dtype=torch.float32, device=W.device)   # slabs, then the (zero) counters
+            d.splitk_ws, d.splitk = _ptr(ws), nsplit
+        self._keep = (A, A2, W, segs, ws) + tuple(keep)
         self._fn = _nat.lib().lwdetr_gemm
         self._ref = C.byref(d)
 
@@ -150,7 +176,7 @@ class RowStatsFinishOp:
     """stats (2, M) planar = (mean, rstd) from the (count, mean, M2) slots the producing GEMM wrote (seg(rowstat_out=...)): no pass over the rows."""
 
     def __init__(self, rowstat, stats, M, C_, eps):
-        assert rowstat.dtype == torch.float32 and stats.dtype == torch.float32 and C_ % 64 == 0 and rowstat.numel() >= (C_ // 64) * M * 3
+        assert rowstat.dtype == torch.float32 and stats.dtype == torch.float32 and C_ % 64 == 0 and rowstat.numel() >= (C_ // 64) * M * 4
         self.args = (_ptr(rowstat), C_ // 64, M, C_, float(eps), _ptr(stats))
         self._keep = (rowstat, stats)
         self._fn = _nat.lib().lwdetr_row_stats_finish

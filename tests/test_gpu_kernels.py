@@ -458,6 +458,58 @@ def test_gemm_with_layernorm_folded_in(dtype, m, c, mode):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("splits", [2, 3, 4])
+def test_gemm_split_k_few_rows(dtype, splits):
+    """Round 5: split-K of the 64 x 64 DMA ring kernel for few-row GEMMs with a long contraction (lwdetr_gemm_desc.splitk / splitk_ws: slices of
+    a tile write f32 slabs, the last arriver sums them in slice order and runs the epilogue) - the single-image shapes: the projector's 3x3
+    convolution (implicit GEMM, SiLU), a 1x1 convolution into a TOKMAP destination shape, a decoder Linear with residual + ragged M / N.
+    Against torch fp32 and against the unsplit launch; repeated launches are bit-identical (the sum does not depend on who arrives last) and
+    leave the arrival counters at zero."""
+    from lwdetr_amd import kernels as K
+    # (a) 3x3 convolution, 40 x 40 pixels, 128 -> 128 channels inside wider rows
+    b, hp, wp, c, ctot, col0 = 1, 40, 40, 128, 256, 64
+    x = _rand(b, hp, wp, ctot, dtype=dtype, seed=1)
+    w = _rand(c, c, 3, 3, dtype=dtype, scale=(9 * c) ** -0.5, seed=2)
+    bias = _rand(c, seed=3)
+    outs = []
+    for sk in (splits, 0, splits):
+        out = torch.zeros(b * hp * wp, c, dtype=dtype, device=_dev())
+        op = K.GemmOp(x.reshape(-1, ctot), w.permute(0, 2, 3, 1).reshape(c, -1).contiguous(), b * hp * wp, c, 9 * c,
+                      [K.seg(out, 0, c, ldo=c, bias=bias, act=K.ACT_SILU)], lda=ctot, a_mode=K.A_CONV3x3, a_tok=K.tok_layout(False, hp, wp, 0),
+                      conv_cin=c, conv_stride=1, a_col0=col0, conv_hout=hp, conv_wout=wp, splitk=sk)
+        assert op.desc.splitk == (sk if sk >= 2 else 0)
+        for _ in range(3):
+            op()
+        torch.cuda.synchronize()
+        if sk >= 2:
+            ws = op._keep[4]
+            tiles = ((b * hp * wp + 63) // 64) * ((c + 63) // 64)
+            assert ws[tiles * sk * K.SPLITK_SLAB:].abs().max().item() == 0          # counters back at zero
+        outs.append(out)
+    ref = F.silu(F.conv2d(x[..., col0:col0 + c].float().permute(0, 3, 1, 2), w.float(), bias, padding=1)).permute(0, 2, 3, 1).reshape(-1, c)
+    assert _relerr(outs[0], ref) < TOL[dtype] and _relerr(outs[1], ref) < TOL[dtype]
+    assert torch.equal(outs[0], outs[2])                                              # bit-reproducible
+    assert _relerr(outs[0], outs[1].float()) < TOL[dtype] / 2
+    # (b) plain GEMMs: ragged M and N, residual + LayerScale, two segments
+    for (m, n, k) in [(1600, 256, 768), (300, 256, 512), (1000, 200, 1024), (77, 64, 2048)]:
+        xa = _rand(m, k, dtype=dtype, seed=4)
+        wa = _rand(n, k, dtype=dtype, scale=k ** -0.5, seed=5)
+        ba, ga = _rand(n, seed=6), _rand(n, seed=7)
+        res = _rand(m, n, dtype=dtype, seed=8)
+        got = []
+        for sk in (splits, 0):
+            o = torch.zeros(m, n, dtype=dtype, device=_dev())
+            K.GemmOp(xa, wa, m, n, k, [K.seg(o, 0, n, ldo=n, bias=ba, gamma=ga, res=res, ldres=n, act=K.ACT_RELU)], splitk=sk)()
+            got.append(o)
+        refp = res.float() + ga * torch.relu(xa.float() @ wa.float().t() + ba)
+        assert _relerr(got[0], refp) < TOL[dtype], (m, n, k)
+        assert _relerr(got[0], got[1].float()) < TOL[dtype] / 2, (m, n, k)
+    # the automatic policy: few rows + long K only
+    assert K.splitk_for(1600, 128, 1152, dtype) >= 2 and K.splitk_for(51200, 128, 1152, dtype) == 1 and K.splitk_for(1600, 256, 256, dtype) == 1
+    assert K.splitk_for(1600, 128, 1152, torch.float32) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("m,n,k,mode", [(1024, 768, 768, -1), (4160, 768, 3072, 2), (4096, 768, 768, 128), (2048, 256, 512, -1), (12800, 768, 768, 2)])
 def test_gemm_row_statistics_from_the_epilogue(dtype, m, n, k, mode):
     """Round 5, producer side of the folded LayerNorm: a GEMM with seg(rowstat_out=...) reports (count, mean, M2) of the rounded outputs of
@@ -470,7 +522,7 @@ def test_gemm_row_statistics_from_the_epilogue(dtype, m, n, k, mode):
     bias, gamma = _rand(n, seed=3), _rand(n, seed=4) * 0.3 + 0.5
     res = (_rand(m, n, dtype=torch.float32, seed=5) * 2 + 6 * _rand(m, 1, dtype=torch.float32, seed=6)).to(dtype)
     out, tap = torch.empty(m, n, dtype=dtype, device=_dev()), torch.zeros(m, 2 * n, dtype=dtype, device=_dev())
-    rowstat = torch.full(((n // 64) * m * 3,), float("nan"), device=_dev())
+    rowstat = torch.zeros((n // 64) * m * 4, device=_dev())           # (count, mean, M2, -) records, zero-initialised once (the contract)
     stats, stats2 = torch.empty(2, m, device=_dev()), torch.empty(2, m, device=_dev())
     _native.lib().lwdetr_gemm_tuning(mode)
     try:
