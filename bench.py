@@ -253,7 +253,7 @@ def run_other_config(size, batch, res, dtype, dev, steps=20, warmup=5):
     assert torch.isfinite(det).all()
     out = {"workload": f"LW-DETR-{size} {res}x{res} batch {batch} {dtype}", "img_s": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
            "steps": steps, "warmup": warmup, "ms_per_step_passes": [round(t / steps * 1e3, 3) for t in passes],
-           "methodology": "first timed pass after the warm-up, as the default workload; later passes listed", "launch_chains": type(model)._chains_for(batch)}
+           "methodology": "first timed pass after the warm-up, as the default workload; later passes listed", "launch_chains": type(model)._chains_for(batch, res, res)}
     gf = GFLOP_PER_IMAGE.get((size, res))
     if gf:
         out["model_mfma_frac"] = round(out["img_s"] * gf / 1e3 / PEAK_TFLOPS[dtype], 4)
@@ -390,7 +390,7 @@ def main():
                                f"{a.dtype}, random-init weights (synthetic COCO-shaped input)",
                    "global_batch": world * a.batch, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                    "collective": "all_gather_into_tensor of (B,K,6) f32 detections" if grouped else "none", "backend": backend,
-                   "launch_chains": type(model)._chains_for(a.batch)},
+                   "launch_chains": type(model)._chains_for(a.batch, a.res, a.res)},
     }
     result["ms_per_step_passes"] = {"timed": round(ms_step, 3), "after": [round(t / a.steps * 1e3, 3) for t in extra_passes],
                                     "note": "value / ms_per_step come from `timed` alone; `after` = three more passes of the same K steps outside the timed region"}

@@ -71,7 +71,8 @@ SPLITK_SLAB = 64 * 68          # floats of one partial 64 x 64 tile in the kerne
 def splitk_for(M, N, K, dtype, has_a2=False):
     """Workgroups per 64 x 64 tile for a few-row GEMM with a long contraction (round 5; the single-image latency path: the 3x3 convolutions
     of the projector are 36 dependent k-stages on 50 tiles): 16-bit, up to 3200 rows, K >= 512, and only while tiles x splits stay within
-    one round of the chip; at least 8 stages of 32 per slice. LWDETR_GEMM_SPLITK=0 switches it off, n forces n where legal."""
+    one round of the chip; at least 8 stages of 32 per slice - that was the policy that was measured; it lost (see below), so the automatic
+    answer is 1 and LWDETR_GEMM_SPLITK=n forces n slices where legal (tests, tuning)."""
     env = os.environ.get("LWDETR_GEMM_SPLITK")
     if dtype not in (torch.float16, torch.bfloat16) or has_a2 or K % 32 != 0:
         return 1
@@ -79,9 +80,11 @@ def splitk_for(M, N, K, dtype, has_a2=False):
     if env is not None:
         n = int(env)
         return n if (n >= 2 and K // 32 >= n) else 1
-    if M > 3200 or K < 512 or tiles > 128:
-        return 1
-    return max(1, min(4, (K // 32) // 8, 256 // tiles))
+    # Measured (tools/lat_bs1.py, single image, LW-DETR-small as one HIP graph; profiles/r5e_single_image_latency.txt): NOT a gain - the
+    # publish / acquire of the slabs (two agent-scope fences + 17 KB per slice through L2) costs what the shorter k-chain saves: 3x3
+    # convolutions (K = 1152, 4 slices) 19.2 -> 17.5 us, every K <= 768 GEMM 1.5-2.5 us SLOWER; p50 0.867 ms without, 0.880 with this policy,
+    # 0.930 / 0.980 ms with 2 / 3 slices everywhere. Off unless LWDETR_GEMM_SPLITK=n asks for it.
+    return 1
 
 
 class GemmOp:

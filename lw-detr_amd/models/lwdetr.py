@@ -129,7 +129,7 @@ class LWDETR(nn.Module):
                     samples.mask = None
             x, mask = samples.tensors, samples.mask
         b, _, h, w = x.shape
-        nch = self._chains_for(b) if (mask is None and _forced_topk is None and isinstance(samples, torch.Tensor)) else 1
+        nch = self._chains_for(b, h, w) if (mask is None and _forced_topk is None and isinstance(samples, torch.Tensor)) else 1
         if nch > 1:
             return self._forward_chains(x, b, h, w, nch, collect=_collect)
         plan = self._plan(b, h, w)
@@ -143,21 +143,23 @@ class LWDETR(nn.Module):
         (the selection is one workgroup per image and would otherwise run alone at the end of the step)."""
         assert isinstance(images, torch.Tensor) and images.dim() == 4
         b, _, h, w = images.shape
-        nch = self._chains_for(b)
+        nch = self._chains_for(b, h, w)
         if nch > 1:
             return self._forward_chains(images, b, h, w, nch, post=(postprocess, target_sizes))
         out = self.forward(images)
         return out, postprocess.select_packed(out["pred_logits"], out["pred_boxes"], target_sizes)
 
     @staticmethod
-    def _chains_for(b):
-        """Launch chains for a dense batch of b images: default two from _TWO_STREAM_MIN_BATCH images; LWDETR_STREAMS / set_streams:
-        1 = one chain, n >= 2 = n chains whenever the batch splits into n parts of at least 8 images."""
+    def _chains_for(b, h=640, w=640):
+        """Launch chains for a dense batch of b images of h x w pixels: default two from _TWO_STREAM_MIN_BATCH images - at 900 x 900 pixels and
+        up already from 16 (round 5: xlarge 960 x 960 B = 16 as two 8-image chains +1.1 % on two boxes, profiles/r5f_*; round 4: +1 %);
+        LWDETR_STREAMS / set_streams: 1 = one chain, n >= 2 = n chains whenever the batch splits into n parts of at least 8 images."""
         if _STREAMS == 1:
             return 1
         if _STREAMS >= 2:
             return _STREAMS if (b % _STREAMS == 0 and b // _STREAMS >= 8) else 1
-        return 2 if (b >= _TWO_STREAM_MIN_BATCH and b % 2 == 0) else 1
+        min_b = _TWO_STREAM_MIN_BATCH if h * w < 900 * 900 else _TWO_STREAM_MIN_BATCH // 2
+        return 2 if (b >= min_b and b % 2 == 0) else 1
 
     def _forward_chains(self, x, b, h, w, nch, post=None, collect=None):
         """The parts of a dense batch as ``nch`` launch chains on ``nch`` streams. Every kernel of the path runs its workgroups in

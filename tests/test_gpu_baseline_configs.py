@@ -77,7 +77,7 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
     x = synth_images(batch, res, res, seed=4321).to(DEV).to(dtype)
     col = {}
     out = model(x, _collect=col)                                            # free-running, in the launch plan bench.py times:
-    expect_chains = type(model)._chains_for(batch)                          # two chains from 32 images (each chain's selection
+    expect_chains = type(model)._chains_for(batch, res, res)                          # two chains from 32 images (each chain's selection
     assert col["launch_chains"] == expect_chains, col["launch_chains"]      # is collected and concatenated)
     ours = col["topk_idx"].cpu().numpy()
     sizes = torch.tensor([[480.0, 640.0]] * batch, device=DEV)

@@ -504,9 +504,8 @@ def test_gemm_split_k_few_rows(dtype, splits):
         refp = res.float() + ga * torch.relu(xa.float() @ wa.float().t() + ba)
         assert _relerr(got[0], refp) < TOL[dtype], (m, n, k)
         assert _relerr(got[0], got[1].float()) < TOL[dtype] / 2, (m, n, k)
-    # the automatic policy: few rows + long K only
-    assert K.splitk_for(1600, 128, 1152, dtype) >= 2 and K.splitk_for(51200, 128, 1152, dtype) == 1 and K.splitk_for(1600, 256, 256, dtype) == 1
-    assert K.splitk_for(1600, 128, 1152, torch.float32) == 1
+    # the automatic policy: off (measured slower on the latency path: kernels.splitk_for)
+    assert K.splitk_for(1600, 128, 1152, dtype) == 1 and K.splitk_for(51200, 128, 1152, dtype) == 1
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
