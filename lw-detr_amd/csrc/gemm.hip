@@ -141,11 +141,14 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                                   (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0)) &&
                                   (!out2 || (sg.ld2 % 8 == 0 && ((size_t)out2 & 15) == 0));      // round 5: the tap copy no longer leaves the fast path
                 if (fast) {
-                    constexpr int G = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
+                    constexpr int G0 = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
                     auto finish_all = [&](auto act_tag, auto ln_tag, auto st_tag) {
                         constexpr int ACT = decltype(act_tag)::value;
                         constexpr bool LN = decltype(ln_tag)::value;
                         constexpr bool ST = decltype(st_tag)::value && (CPRW & (CPRW - 1)) == 0 && CPRW <= 32;      // producer-side row statistics
+                        // rows in flight per thread: the statistics body needs ~24 more registers per row in flight - two at a time there (four
+                        // spilled into scratch inside the row loop in the 256-register large-tile kernel: +25 us per launch)
+                        constexpr int G = (ST && G0 > 2) ? 2 : G0;
                         float cs[LN ? 8 : 1];
                         if constexpr (LN) {
                             const f32x4 c0 = *(const f32x4*)(sg.ln_colsum + nl), c1 = *(const f32x4*)(sg.ln_colsum + nl + 4);
