@@ -94,16 +94,11 @@ typedef struct {           /* one column segment [n_begin, n_end) of the output 
     long out_row_offset;   /* TOKMAP / DECONV2x2: first row inside an image (level offset into `memory`) */
     /* LayerNorm folded into the GEMM (round 5; `nn.LayerNorm` in front of a Linear, models/backbone/vit.py:199, :217): with W' = W diag(g),
        b' = b + W beta packed by the host, LN(x) W^T + b = rstd_m (x_m . W'_n - mean_m colsum_n) + b'_n - the GEMM reads the RAW rows and the
-       epilogue applies the row statistics: acc <- (acc - mean * ln_colsum[n]) * rstd before bias / activation. */
+       epilogue applies the row statistics: acc <- (acc - mean * ln_colsum[n]) * rstd before bias / activation. All segments of a launch or
+       none; served by the 256 x 256 large-tile kernel only (16-bit, PLAIN A, K % 64 == 0, segment boundaries at multiples of 256):
+       LWDETR_ERR_UNSUPPORTED for any other shape. */
     const float* ln_stats; /* optional (2, M) f32, planar: ln_stats[m] = mean, ln_stats[M + m] = rstd of A row m (lwdetr_row_stats); NULL = plain GEMM */
     const float* ln_colsum;/* with ln_stats: f32 sum over k of W[n][k] as stored (16-bit rounded), indexed by n - n_begin, padded like bias */
-    float* rowstat_out;    /* optional PRODUCER side of the same fold: per 64-column slot s = n / 64 and row m a 16-byte record (count, mean, M2, -)
-                              of the ROUNDED outputs this launch writes - rowstat_out[(s * M + m) * 4 ..]; a column tile wider than 64 reports in
-                              its first slot only, so the buffer must be ZERO-INITIALISED once and belong to ONE producing GEMM (one tile width):
-                              slots it never writes keep count 0. lwdetr_row_stats_finish merges the slots of a row (pairwise mean / M2 update)
-                              into (mean, rstd): the next LayerNorm's statistics without another pass over the rows. Contract (else
-                              LWDETR_ERR_UNSUPPORTED): 16-bit, LINEAR mode, no rowmask, M % 64 == 0, n_begin and n_end multiples of 256, 16-byte
-                              aligned rows (ldo, ldres, ld2 multiples of 8 elements). */
 } lwdetr_gemm_seg;
 
 typedef struct {
@@ -134,8 +129,6 @@ int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
  * two-pass f32 on the stored values -
  * the arithmetic of lwdetr_layernorm without its output pass (half its HBM traffic). C % 8 == 0 (16-bit) / C % 4 == 0 (f32). */
 int lwdetr_row_stats(const void* x, long ldx, long M, int C, float eps, float* stats, int dtype, void* hip_stream);
-/* (mean, rstd) per row, planar (2, M), from the (count, mean, M2, -) records a GEMM wrote through lwdetr_gemm_seg.rowstat_out (nslots = C / 64). */
-int lwdetr_row_stats_finish(const float* rowstat, int nslots, long M, int C, float eps, float* stats, void* hip_stream);
 /* Kernel selection override for tests / tuning (process-wide): big_mode -1 = default (environment LWDETR_GEMM_BIG, else
  * shape thresholds), 0 = never use the 256-row large-tile kernel, 2 = use it whenever the shape is legal for it,
  * 32 / 64 = as 2 with that stage depth. Results do not depend on it beyond f32 summation order. */

@@ -35,7 +35,7 @@ class GemmSeg(C.Structure):
                 ("mode", C.c_int), ("n_begin", C.c_int), ("n_end", C.c_int), ("ldo", C.c_long), ("ld2", C.c_long),
                 ("ldres", C.c_long), ("res_mod", C.c_int), ("rowmask_after", C.c_int), ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int),
                 ("in_tok", TokLayout), ("out_tok", TokLayout), ("out_batch_stride", C.c_long),
-                ("out_row_offset", C.c_long), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("rowstat_out", C.c_void_p)]
+                ("out_row_offset", C.c_long), ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -95,7 +95,6 @@ def lib():
         l.lwdetr_layernorm.argtypes = [vp, lg, vp, vp, vp, lg, lg, i, f, lg, lg, lg, i, vp]
         l.lwdetr_layernorm_chain.argtypes = [vp, lg, vp, vp, f, vp, lg, vp, vp, f, vp, lg, lg, i, i, vp]
         l.lwdetr_row_stats.argtypes = [vp, lg, lg, i, f, vp, i, vp]
-        l.lwdetr_row_stats_finish.argtypes = [vp, i, lg, i, f, vp, vp]
         l.lwdetr_ffn_splits.argtypes = [lg, i, i, i]
         l.lwdetr_ffn_partial.argtypes = [vp, lg, vp, vp, vp, vp, lg, i, i, i, vp]
         l.lwdetr_ffn_finish.argtypes = [vp, lg, vp, i, vp, vp, vp, f, vp, lg, vp, vp, f, vp, lg, lg, i, i, vp]
@@ -141,7 +140,7 @@ def lib():
         l.lwdetr_prof_kernel_name.restype = C.c_char_p
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
         for fn in ("lwdetr_msda_forward", "lwdetr_msda_backward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
-                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_row_stats", "lwdetr_row_stats_finish", "lwdetr_enc_chain", "lwdetr_row_chain", "lwdetr_mlp_fused", "lwdetr_vit_block", "lwdetr_vit_qkv", "lwdetr_vit_stem", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
+                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_row_stats", "lwdetr_enc_chain", "lwdetr_row_chain", "lwdetr_mlp_fused", "lwdetr_vit_block", "lwdetr_vit_qkv", "lwdetr_vit_stem", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
                    "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_postprocess_packed", "lwdetr_finalize_outputs", "lwdetr_resize_normalize", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int
         _lib = l

@@ -66,34 +66,19 @@ __device__ __forceinline__ void store_run(T* dst, const float* x, int cnt, bool 
     }
 }
 
-// all-reduce (sum) over aligned groups of NL = 8 / 16 / 32 neighbouring lanes on the VALU: xor 1, 2 as quad permutes, then mirrors inside 8 and
-// 16 lanes (every lane of a reduced sub-group already holds its sum, so a mirror pairs the sub-groups exactly as an xor would), then a
-// v_permlane16_swap across the two rows of a 32-lane half
-template <int NL> __device__ __forceinline__ float row_allreduce_sum(float v) {
-    static_assert(NL == 8 || NL == 16 || NL == 32, "8, 16 or 32 lanes");
-    auto dpp_add = [](float x, auto ctrl) {
-        const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true);
-        return x + __int_as_float(y);
-    };
-    v = dpp_add(v, std::integral_constant<int, 0xB1>{});        // quad_perm [1, 0, 3, 2]
-    v = dpp_add(v, std::integral_constant<int, 0x4E>{});        // quad_perm [2, 3, 0, 1]
-    v = dpp_add(v, std::integral_constant<int, 0x141>{});       // row_half_mirror
-    if constexpr (NL >= 16) v = dpp_add(v, std::integral_constant<int, 0x140>{});      // row_mirror
-    if constexpr (NL == 32) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    return v;
-}
-
-// ---- shared epilogue: accumulators -> LDS (f32) -> fused bias / activation / scale / LayerScale / residual / masks ->
+// ---- the same epilogue with a LayerNorm folded into the GEMM (round 5; lwdetr_gemm_seg.ln_stats / ln_colsum): acc <- (acc - mean_m * colsum_n) *
+// rstd_m before the bias. A COPY of epilogue_finish on purpose: with the LayerNorm arithmetic as a run-time (or even as an extra instantiated)
+// branch of the shared function, every kernel that inlines it got a different register allocation and schedule - the 256 x 256 large-tile
+// kernel, at its 256-register limit, 15-20 % slower on the plain GEMMs of xlarge (same box, profiles/r5g_gemm_big_regression_bisect.txt).
+// The plain kernels keep round 4's function below, byte for byte; only the kernels instantiated for folded GEMMs see this one.
+// ---- accumulators -> LDS (f32) -> fused LayerNorm / bias / activation / scale / LayerScale / residual / masks ->
 // coalesced 16-byte stores in the destination layout of the tile's column segment.
 // Second half of the epilogue, shared by every GEMM kernel: one pass of 64 tile rows, already staged in LDS as f32
 // (ROW orientation: stage[row * (BN + 4) + col]; COL orientation (HEADS_T): stage[col * 68 + row]), is finished by all
 // NTHR threads of the workgroup in runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores; the
 // mode / activation logic lives in a small loop instead of being replicated per accumulator register.
 template <typename T, int BN, int NTHR, int FAST_GROUP = 2>   // FAST_GROUP: sweeps the fast path keeps in flight (registers)
-__device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
+__device__ __forceinline__ void epilogue_finish_ln(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
                                                 const float* stage, long mbase, int n0) {
     typedef typename Vec<T>::v8 V8;
     const int tid = threadIdx.x;
@@ -123,9 +108,13 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { gv[e] = g0[e]; gv[4 + e] = g1[e]; }
                 }
-                // LayerNorm folded into the GEMM (ln_stats): acc <- (acc - mean_m * colsum_n) * rstd_m before the bias. The fast path is
-                // instantiated with and without it (a run-time test kept 16 more registers live in every GEMM: spills in the 256 x 256 kernel)
-                const float* __restrict__ lnst = sg.ln_stats;
+                const float* __restrict__ lnst = sg.ln_stats;          // planar (2, M): mean, rstd
+                float cs[8];
+                {
+                    const f32x4 c0 = *(const f32x4*)(sg.ln_colsum + nl), c1 = *(const f32x4*)(sg.ln_colsum + nl + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cs[e] = c0[e]; cs[4 + e] = c1[e]; }
+                }
                 const long coff = col_offset(sg, nl);
                 const int act = sg.act;
                 const float scale = sg.scale;
@@ -135,53 +124,35 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                 // masks and alignment in every sweep, which serialises the sweeps behind each other's memory latency
                 // (measured on the 256 x 256 tile kernel: 9-12 us of epilogue per tile).
                 constexpr int ITS = 64 / RSTEP;
-                const bool fast = 64 % RSTEP == 0 && mbase + 64 <= d.M && !sg.rowmask && (n_end - n0) % 8 == 0 &&
+                const bool fast = 64 % RSTEP == 0 && mbase + 64 <= d.M && !sg.rowmask && !out2 && (n_end - n0) % 8 == 0 &&
                                   (sg.mode == LWDETR_OUT_LINEAR || sg.mode == LWDETR_OUT_HEADS) && sg.ldo % 8 == 0 &&
                                   ((size_t)out & 15) == 0 && (sg.mode == LWDETR_OUT_LINEAR || sg.p1 % 8 == 0) && sg.n_begin % 8 == 0 &&
-                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0)) &&
-                                  (!out2 || (sg.ld2 % 8 == 0 && ((size_t)out2 & 15) == 0));      // round 5: the tap copy no longer leaves the fast path
+                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0));
                 if (fast) {
-                    constexpr int G0 = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
-                    auto finish_all = [&](auto act_tag, auto ln_tag, auto st_tag) {
+                    constexpr int G = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
+                    auto finish_all = [&](auto act_tag) {
                         constexpr int ACT = decltype(act_tag)::value;
-                        constexpr bool LN = decltype(ln_tag)::value;
-                        constexpr bool ST = decltype(st_tag)::value && (CPRW & (CPRW - 1)) == 0 && CPRW <= 32;      // producer-side row statistics
-                        // rows in flight per thread: the statistics body needs ~24 more registers per row in flight - two at a time there (four
-                        // spilled into scratch inside the row loop in the 256-register large-tile kernel: +25 us per launch)
-                        constexpr int G = (ST && G0 > 2) ? 2 : G0;
-                        float cs[LN ? 8 : 1];
-                        if constexpr (LN) {
-                            const f32x4 c0 = *(const f32x4*)(sg.ln_colsum + nl), c1 = *(const f32x4*)(sg.ln_colsum + nl + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { cs[e] = c0[e]; cs[4 + e] = c1[e]; }
-                        }
 #pragma unroll 1
                         for (int it0 = 0; it0 < ITS; it0 += G) {
                             f32x4 a0[G], a1[G];
                             V8 rv[G];
                             long ro[G];
-                            float lmean[LN ? G : 1], lrstd[LN ? G : 1];
+                            float lmean[G], lrstd[G];
 #pragma unroll
                             for (int g = 0; g < G; ++g) {
                                 const int row = tid / CPRW + (it0 + g) * RSTEP;
                                 const long m = mbase + row;
-                                if constexpr (LN) { lmean[g] = lnst[m]; lrstd[g] = lnst[(long)d.M + m]; }
+                                lmean[g] = lnst[m]; lrstd[g] = lnst[(long)d.M + m];
                                 if (sg.mode == LWDETR_OUT_LINEAR) ro[g] = m * sg.ldo;
                                 else { const int b = (int)(m / sg.p0), t = (int)(m - (long)b * sg.p0); ro[g] = ((long)b * sg.p2 * sg.p0 + t) * sg.p1; }
                                 a0[g] = *(const f32x4*)(stage + row * SLD + col);
                                 a1[g] = *(const f32x4*)(stage + row * SLD + col + 4);
                             }
-                            float pivv[ST ? G : 1];
-#pragma unroll
-                            for (int g = 0; g < (ST ? G : 1); ++g) pivv[g] = 0.f;
                             if (res) {
 #pragma unroll
                                 for (int g = 0; g < G; ++g) {
                                     const long m = mbase + tid / CPRW + (it0 + g) * RSTEP;
                                     rv[g] = *(const V8*)(res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl);
-                                    // pivot of the row statistics (below): the residual's first element of this tile, fetched WITH the residual
-                                    // (a load behind the output stores makes hipcc drain them: vmcnt counts both)
-                                    if constexpr (ST) pivv[g] = to_f32<T>(res[(sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + (n0 - sg.n_begin)]);
                                 }
                             }
 #pragma unroll
@@ -189,12 +160,8 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                                 float x[8];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    if constexpr (LN) {
-                                        x[e] = fmaf(fmaf(-lmean[g], cs[e], a0[g][e]), lrstd[g], bv[e]);
-                                        x[4 + e] = fmaf(fmaf(-lmean[g], cs[4 + e], a1[g][e]), lrstd[g], bv[4 + e]);
-                                    } else {
-                                        x[e] = a0[g][e] + bv[e]; x[4 + e] = a1[g][e] + bv[4 + e];
-                                    }
+                                    x[e] = fmaf(fmaf(-lmean[g], cs[e], a0[g][e]), lrstd[g], bv[e]);
+                                    x[4 + e] = fmaf(fmaf(-lmean[g], cs[4 + e], a1[g][e]), lrstd[g], bv[4 + e]);
                                 }
                                 if (ACT != ACT_NONE) {
 #pragma unroll
@@ -210,48 +177,12 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(x[e]);
                                 *(V8*)(out + ro[g] + coff) = o;
-                                const long mrow = mbase + tid / CPRW + (it0 + g) * RSTEP;
-                                if (out2) *(V8*)(out2 + mrow * sg.ld2 + nl) = o;
-                                if constexpr (ST) {
-                                    {
-                                        // producer side of the folded LayerNorm: (count, mean, M2) of this tile's BN rounded outputs of the row.
-                                        // One pass: sums of (v - p) and (v - p)^2 around a pivot every lane of the row knows without talking to
-                                        // the others - the residual's first element of this tile (the row's old value there: within a few
-                                        // standard deviations of the new mean, which is all the cancellation in S2 - S1^2 / n needs) - then one
-                                        // all-reduce of the two sums over the row's CPRW lanes on the VALU (DPP butterflies inside 16 lanes,
-                                        // a permlane16 swap across them; the first form used ds_bpermute shuffles and a second pass for the
-                                        // deviations: +25 us per producing launch, profiles/r5d_*)
-                                        const float piv = pivv[g];
-                                        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                                        for (int e = 0; e < 8; ++e) { const float dv = to_f32<T>(o[e]) - piv; s1 += dv; s2 = fmaf(dv, dv, s2); }
-                                        s1 = row_allreduce_sum<CPRW>(s1); s2 = row_allreduce_sum<CPRW>(s2);
-                                        const float mt = piv + s1 * (1.f / BN), m2 = fmaxf(s2 - s1 * s1 * (1.f / BN), 0.f);
-                                        // ONE 16-byte store per row and tile (the first form wrote six dwords - count / mean / M2 and zero
-                                        // counts for the other slots the tile covers: 7x the store instructions of the epilogue, +25 us per
-                                        // launch). Slots a launch never writes keep the count 0 the host initialised them with: a rowstat
-                                        // buffer belongs to ONE producing GEMM (one column tile width).
-                                        if (tid % CPRW == 0)
-                                            *(f32x4*)(sg.rowstat_out + ((long)(n / 64) * d.M + mrow) * 4) = f32x4{(float)BN, mt, m2, 0.f};
-                                    }
-                                }
                             }
                         }
                     };
-                    // instantiated per feature: a run-time test of the rarely used ones keeps their registers live in every GEMM (the 256 x 256
-                    // kernel sits at its 256-register limit: 36 spilled registers with both tests inside one body, none with three bodies)
-                    if (lnst) {         // LayerNorm in front of a Linear: no activation (QKV) or GELU (fc1); anything else takes the general loop
-                        if (act == ACT_NONE) { finish_all(std::integral_constant<int, ACT_NONE>{}, std::true_type{}, std::false_type{}); return; }
-                        if (act == ACT_GELU) { finish_all(std::integral_constant<int, ACT_GELU>{}, std::true_type{}, std::false_type{}); return; }
-                    } else if (sg.rowstat_out) {       // producer of a folded LayerNorm's rows: projection / fc2 / patch embedding (no activation)
-                        if (act == ACT_NONE && (CPRW & (CPRW - 1)) == 0 && CPRW <= 32) { finish_all(std::integral_constant<int, ACT_NONE>{}, std::false_type{}, std::true_type{}); return; }
-                    } else {
-                        if (act == ACT_NONE) finish_all(std::integral_constant<int, ACT_NONE>{}, std::false_type{}, std::false_type{});
-                        else if (act == ACT_GELU) finish_all(std::integral_constant<int, ACT_GELU>{}, std::false_type{}, std::false_type{});
-                        else if (act == ACT_SILU) finish_all(std::integral_constant<int, ACT_SILU>{}, std::false_type{}, std::false_type{});
-                        else finish_all(std::integral_constant<int, ACT_RELU>{}, std::false_type{}, std::false_type{});
-                        return;
-                    }
+                    // a LayerNorm in front of a Linear: no activation (QKV) or GELU (fc1); anything else takes the general loop
+                    if (act == ACT_NONE) { finish_all(std::integral_constant<int, ACT_NONE>{}); return; }
+                    if (act == ACT_GELU) { finish_all(std::integral_constant<int, ACT_GELU>{}); return; }
                 }
 #pragma unroll
                 for (int it = 0; it < (64 + RSTEP - 1) / RSTEP; ++it) {
@@ -271,10 +202,10 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { x[e] = keep_acc ? a0[e] : 0.f; x[4 + e] = keep_acc ? a1[e] : 0.f; }
                     }
-                    if (lnst) {
+                    {
                         const float mean = lnst[m], rstd = lnst[(long)d.M + m];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) x[e] = keep_acc ? fmaf(-mean, sg.ln_colsum[nl + e], x[e]) * rstd : 0.f;
+                        for (int e = 0; e < 8; ++e) x[e] = keep_acc ? fmaf(-mean, cs[e], x[e]) * rstd : 0.f;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] += bv[e];
@@ -318,11 +249,9 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                     const bool al = (((size_t)obase | ((size_t)sg.p0 * sizeof(T))) & (4 * sizeof(T) - 1)) == 0;
                     const int act = sg.act;
                     const float scale = sg.scale;
-                    float lm[4] = {0.f, 0.f, 0.f, 0.f}, lr[4] = {1.f, 1.f, 1.f, 1.f};     // LayerNorm folded into the GEMM: this thread's 4 rows
-                    if (sg.ln_stats) {
+                    float lm[4] = {0.f, 0.f, 0.f, 0.f}, lr[4] = {1.f, 1.f, 1.f, 1.f};     // this thread's 4 rows
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (e < cnt) { lm[e] = sg.ln_stats[m + e]; lr[e] = sg.ln_stats[(long)d.M + m + e]; }
-                    }
+                    for (int e = 0; e < 4; ++e) if (e < cnt) { lm[e] = sg.ln_stats[m + e]; lr[e] = sg.ln_stats[(long)d.M + m + e]; }
 #pragma unroll 4
                     for (int coln = tid / RPC; coln < BN; coln += NTHR / RPC) {
                         const int n = n0 + coln;
@@ -330,7 +259,7 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                         const int nl = n - sg.n_begin;
                         const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
                         const float bias = sg.bias ? sg.bias[nl] : 0.f;
-                        const float csn = sg.ln_stats ? sg.ln_colsum[nl] : 0.f;
+                        const float csn = sg.ln_colsum[nl];
                         float x[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(fmaf(fmaf(-lm[e], csn, a0[e]), lr[e], bias), act) * scale;
@@ -347,14 +276,213 @@ __device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const
                     const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
                     const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
                     const float bias = sg.bias ? sg.bias[nl] : 0.f;
-                    const float csn = sg.ln_stats ? sg.ln_colsum[nl] : 0.f;
+                    const float csn = sg.ln_colsum[nl];
                     float x[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float mean = 0.f, rstd = 1.f;
-                        if (sg.ln_stats && e < cnt) { mean = sg.ln_stats[m + e]; rstd = sg.ln_stats[(long)d.M + m + e]; }
+                        if (e < cnt) { mean = sg.ln_stats[m + e]; rstd = sg.ln_stats[(long)d.M + m + e]; }
                         x[e] = act_apply<T>(fmaf(fmaf(-mean, csn, a0[e]), rstd, bias), sg.act) * sg.scale;
                     }
+                    const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
+                    T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
+                    store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
+                }
+            }
+        }
+    }
+}
+
+
+// ---- shared epilogue: accumulators -> LDS (f32) -> fused bias / activation / scale / LayerScale / residual / masks ->
+// coalesced 16-byte stores in the destination layout of the tile's column segment.
+// Second half of the epilogue, shared by every GEMM kernel: one pass of 64 tile rows, already staged in LDS as f32
+// (ROW orientation: stage[row * (BN + 4) + col]; COL orientation (HEADS_T): stage[col * 68 + row]), is finished by all
+// NTHR threads of the workgroup in runs of 8 consecutive outputs (4 for HEADS_T) - coalesced 16-byte global stores; the
+// mode / activation logic lives in a small loop instead of being replicated per accumulator register.
+template <typename T, int BN, int NTHR, int FAST_GROUP = 2>   // FAST_GROUP: sweeps the fast path keeps in flight (registers)
+__device__ __forceinline__ void epilogue_finish(const lwdetr_gemm_desc& d, const lwdetr_gemm_seg& sg, bool col_orient,
+                                                const float* stage, long mbase, int n0) {
+    typedef typename Vec<T>::v8 V8;
+    const int tid = threadIdx.x;
+    constexpr int SLD = BN + 4, SLD_T = 64 + 4;
+    const int n_end = sg.n_end < d.N ? sg.n_end : d.N;
+    T* __restrict__ out = (T*)sg.out;
+    {
+        if (!col_orient) {
+            // thread -> fixed 8-column run (col), rows strided by 256 / CPRW: column parameters are loop invariant and
+            // fetched with two 16-byte loads each (bias / gamma buffers are padded to a multiple of 8 floats by the host)
+            constexpr int CPRW = BN / 8, RSTEP = NTHR / CPRW;       // threads per row, rows per sweep (floor: BN = 192 leaves 8 idle)
+            T* __restrict__ out2 = (T*)sg.out2;
+            const T* __restrict__ res = (const T*)sg.res;
+            const int col = (tid % CPRW) * 8, n = n0 + col;
+            if (n < n_end && tid < RSTEP * CPRW) {
+                const int nl = n - sg.n_begin, cnt = n_end - n < 8 ? n_end - n : 8;
+                float bv[8], gv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bv[e] = 0.f; gv[e] = 1.f; }
+                if (sg.bias) {
+                    const f32x4 b0 = *(const f32x4*)(sg.bias + nl), b1 = *(const f32x4*)(sg.bias + nl + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                }
+                if (sg.gamma) {
+                    const f32x4 g0 = *(const f32x4*)(sg.gamma + nl), g1 = *(const f32x4*)(sg.gamma + nl + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { gv[e] = g0[e]; gv[4 + e] = g1[e]; }
+                }
+                const long coff = col_offset(sg, nl);
+                const int act = sg.act;
+                const float scale = sg.scale;
+                // Fast path (workgroup-uniform test): all 64 rows exist, whole 16-byte runs, no masks / second destination,
+                // separable LINEAR / HEADS addressing. Straight-line code - the stage reads and residual loads of all
+                // sweeps are issued together, then the arithmetic, then the stores; the general loop below branches on mode,
+                // masks and alignment in every sweep, which serialises the sweeps behind each other's memory latency
+                // (measured on the 256 x 256 tile kernel: 9-12 us of epilogue per tile).
+                constexpr int ITS = 64 / RSTEP;
+                const bool fast = 64 % RSTEP == 0 && mbase + 64 <= d.M && !sg.rowmask && !out2 && (n_end - n0) % 8 == 0 &&
+                                  (sg.mode == LWDETR_OUT_LINEAR || sg.mode == LWDETR_OUT_HEADS) && sg.ldo % 8 == 0 &&
+                                  ((size_t)out & 15) == 0 && (sg.mode == LWDETR_OUT_LINEAR || sg.p1 % 8 == 0) && sg.n_begin % 8 == 0 &&
+                                  (!res || (sg.ldres % 8 == 0 && ((size_t)res & 15) == 0));
+                if (fast) {
+                    constexpr int G = ITS < FAST_GROUP ? (ITS > 0 ? ITS : 1) : FAST_GROUP;
+                    auto finish_all = [&](auto act_tag) {
+                        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll 1
+                        for (int it0 = 0; it0 < ITS; it0 += G) {
+                            f32x4 a0[G], a1[G];
+                            V8 rv[G];
+                            long ro[G];
+#pragma unroll
+                            for (int g = 0; g < G; ++g) {
+                                const int row = tid / CPRW + (it0 + g) * RSTEP;
+                                const long m = mbase + row;
+                                if (sg.mode == LWDETR_OUT_LINEAR) ro[g] = m * sg.ldo;
+                                else { const int b = (int)(m / sg.p0), t = (int)(m - (long)b * sg.p0); ro[g] = ((long)b * sg.p2 * sg.p0 + t) * sg.p1; }
+                                a0[g] = *(const f32x4*)(stage + row * SLD + col);
+                                a1[g] = *(const f32x4*)(stage + row * SLD + col + 4);
+                            }
+                            if (res) {
+#pragma unroll
+                                for (int g = 0; g < G; ++g) {
+                                    const long m = mbase + tid / CPRW + (it0 + g) * RSTEP;
+                                    rv[g] = *(const V8*)(res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl);
+                                }
+                            }
+#pragma unroll
+                            for (int g = 0; g < G; ++g) {
+                                float x[8];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { x[e] = a0[g][e] + bv[e]; x[4 + e] = a1[g][e] + bv[4 + e]; }
+                                if (ACT != ACT_NONE) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) x[e] = act_apply<T>(x[e], ACT);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) x[e] = x[e] * scale * gv[e];
+                                if (res) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(rv[g][e]);
+                                }
+                                V8 o;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(x[e]);
+                                *(V8*)(out + ro[g] + coff) = o;
+                            }
+                        }
+                    };
+                    if (act == ACT_NONE) finish_all(std::integral_constant<int, ACT_NONE>{});
+                    else if (act == ACT_GELU) finish_all(std::integral_constant<int, ACT_GELU>{});
+                    else if (act == ACT_SILU) finish_all(std::integral_constant<int, ACT_SILU>{});
+                    else finish_all(std::integral_constant<int, ACT_RELU>{});
+                    return;
+                }
+#pragma unroll
+                for (int it = 0; it < (64 + RSTEP - 1) / RSTEP; ++it) {
+                    const int row = tid / CPRW + it * RSTEP;
+                    const long m = mbase + row;
+                    long roff;
+                    if (row >= 64 || m >= d.M || !row_offset(sg, m, roff)) continue;
+                    bool keep_acc = true, keep_out = true;
+                    if (sg.rowmask) {
+                        const bool rm = sg.rowmask[m] != 0;
+                        keep_acc = rm || sg.rowmask_after; keep_out = rm || !sg.rowmask_after;
+                    }
+                    float x[8];
+                    {
+                        const f32x4 a0 = *(const f32x4*)(stage + row * SLD + col);
+                        const f32x4 a1 = *(const f32x4*)(stage + row * SLD + col + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { x[e] = keep_acc ? a0[e] : 0.f; x[4 + e] = keep_acc ? a1[e] : 0.f; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += bv[e];
+                    if (act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = act_apply<T>(x[e], act);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = x[e] * scale * gv[e];
+                    if (res) {
+                        const T* rp = res + (sg.res_mod > 0 ? m % sg.res_mod : m) * sg.ldres + nl;
+                        if (cnt == 8 && ((size_t)rp & 15) == 0) {
+                            const V8 rv = *(const V8*)rp;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] += to_f32<T>(rv[e]);
+                        } else {
+                            for (int e = 0; e < cnt; ++e) x[e] += to_f32<T>(rp[e]);
+                        }
+                    }
+                    if (!keep_out) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+                    }
+                    T* dst = out + roff + coff;
+                    store_run<T, 8>(dst, x, cnt, ((size_t)dst & 15) == 0);
+                    if (out2) { T* d2 = out2 + m * sg.ld2 + nl; store_run<T, 8>(d2, x, cnt, ((size_t)d2 & 15) == 0); }
+                }
+            }
+        } else {
+            // HEADS_T: out[((b*heads+h)*hd+dd)*Tp + t]: runs of 4 consecutive tokens of one output column. A thread keeps
+            // its token run for the whole sweep when NTHR is a multiple of the 16 runs of a column (image index and token
+            // offset - two divisions - are computed once; round 1 redid them, in 64 bits, for every run).
+            constexpr int RPC = 64 / 4;
+            if (NTHR % RPC == 0) {
+                const int row = (tid % RPC) * 4;
+                const long m = mbase + row;
+                if (m < d.M) {
+                    const int cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
+                    const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
+                    T* obase = out + (long)b * sg.p2 * sg.p1 * sg.p0 + tk;
+                    const bool al = (((size_t)obase | ((size_t)sg.p0 * sizeof(T))) & (4 * sizeof(T) - 1)) == 0;
+                    const int act = sg.act;
+                    const float scale = sg.scale;
+#pragma unroll 4
+                    for (int coln = tid / RPC; coln < BN; coln += NTHR / RPC) {
+                        const int n = n0 + coln;
+                        if (n >= n_end) break;
+                        const int nl = n - sg.n_begin;
+                        const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
+                        const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                        float x[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, act) * scale;
+                        store_run<T, 4>(obase + (long)nl * sg.p0, x, cnt, al);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int c = tid; c < BN * RPC; c += NTHR) {
+                    const int coln = c / RPC, row = (c - coln * RPC) * 4;
+                    const long m = mbase + row;
+                    const int n = n0 + coln;
+                    if (m >= d.M || n >= n_end) continue;
+                    const int nl = n - sg.n_begin, cnt = d.M - m < 4 ? (int)(d.M - m) : 4;
+                    const f32x4 a0 = *(const f32x4*)(stage + coln * SLD_T + row);
+                    const float bias = sg.bias ? sg.bias[nl] : 0.f;
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = act_apply<T>(a0[e] + bias, sg.act) * sg.scale;
                     const int b = (int)(m / sg.p0), tk = (int)(m - (long)b * sg.p0);
                     T* dst = out + ((long)b * sg.p2 * sg.p1 + nl) * sg.p0 + tk;
                     store_run<T, 4>(dst, x, cnt, ((size_t)dst & (4 * sizeof(T) - 1)) == 0);
@@ -1137,8 +1265,8 @@ extern "C" int lwdetr_debug_big_timing(unsigned long long* out) {
 // form spends a third of its time in its prologue (first stages on their way from HBM, every workgroup of the chip at once) and its
 // epilogue (256 KB through LDS, 128 KB of stores) with the CU's matrix pipes idle; with a second, independent workgroup on the CU
 // one tile's epilogue / prologue runs beside the other's k-loop (profiles/r5a_*).
-template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN, int BM = 256, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(const lwdetr_gemm_desc d) {
+template <typename T, int BN, int KB, int NST, int AMODE, int BM, int NW, bool LN = false>
+__device__ __forceinline__ void gemm_big_body(const lwdetr_gemm_desc& d) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     static_assert((NW == 8 && BM == 256) || (NW == 4 && BM == 128), "8 waves x 256 rows or 4 waves x 128 rows");
     constexpr int EPC = 8;
@@ -1374,7 +1502,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
 #endif
 #pragma unroll 1
             for (int slot = 0; slot < EPI_SLOTS; ++slot)       // not unrolled: the accumulators of the later passes are still live
-                epilogue_finish<T, BN, NW * 64, 4>(d, sg, COL, stg + slot * (COL ? BN * SLD_T : 64 * SLD), m0 + (slot * EPI_PASSES + pass) * 64, n0);
+                if constexpr (LN) epilogue_finish_ln<T, BN, NW * 64, 4>(d, sg, COL, stg + slot * (COL ? BN * SLD_T : 64 * SLD), m0 + (slot * EPI_PASSES + pass) * 64, n0);
+                else epilogue_finish<T, BN, NW * 64, 4>(d, sg, COL, stg + slot * (COL ? BN * SLD_T : 64 * SLD), m0 + (slot * EPI_PASSES + pass) * 64, n0);
 #ifdef LWDETR_BIG_TIMING
             const unsigned long long t2_ = BIG_NOW();
 #endif
@@ -1395,9 +1524,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_big_kernel(cons
     if (col_orient) body(std::true_type{});
     else body(std::false_type{});
 }
+// Two entry points, because the launch bounds differ: the 8-wave form keeps round 2's plain __launch_bounds__(512) - with a second argument
+// (amdgpu_waves_per_eu) hipcc schedules the SAME body differently and the QKV launch of xlarge (HEADS / HEADS_T epilogues) ran 20 % slower
+// (260 -> 312 us, same box: profiles/r5g_*) - and the 4-wave form asks for two workgroups per CU.
+template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d) { gemm_big_body<T, BN, KB, NST, AMODE, 256, 8>(d); }
+template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
+__global__ __launch_bounds__(256, 2) void gemm_big4_kernel(const lwdetr_gemm_desc d) { gemm_big_body<T, BN, KB, NST, AMODE, 128, 4>(d); }
+// the 256 x 256 tile with the LayerNorm-folded epilogue (every segment of the launch carries ln_stats): its own kernel, see epilogue_finish_ln
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_big_ln_kernel(const lwdetr_gemm_desc d) { gemm_big_body<T, 256, 64, 2, LWDETR_A_PLAIN, 256, 8, true>(d); }
 
-template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN, int BM = 256, int NW = 8>
+template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN, int BM = 256, int NW = 8, bool LN = false>
 int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
+    static_assert(!LN || (BN == 256 && KB == 64 && NST == 2 && AMODE == LWDETR_A_PLAIN && NW == 8), "the LayerNorm-folded epilogue exists for the 256 x 256 tile");
     constexpr size_t ring = (size_t)NST * (BM + BN) * KB * sizeof(T);
     constexpr size_t stg = (size_t)((BM / 64) / (BN == 128 ? 1 : 2)) * (64 * (BN + 4) > BN * 68 ? 64 * (BN + 4) : BN * 68) * sizeof(float);
     constexpr size_t lds = ring > stg ? ring : stg;
@@ -1407,12 +1547,19 @@ int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_UNSUPPORTED;
     if (state[dev] == 0)
-        state[dev] = hipFuncSetAttribute((const void*)gemm_big_kernel<T, BN, KB, NST, AMODE, BM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         NW == 4 ? 80 * 1024 : 160 * 1024) == hipSuccess ? 1 : -1;
+    {
+        const void* fn;
+        if constexpr (LN) fn = (const void*)gemm_big_ln_kernel<T>;
+        else if constexpr (NW == 4) fn = (const void*)gemm_big4_kernel<T, BN, KB, NST, AMODE>;
+        else fn = (const void*)gemm_big_kernel<T, BN, KB, NST, AMODE>;
+        state[dev] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NW == 4 ? 80 * 1024 : 160 * 1024) == hipSuccess ? 1 : -1;
+    }
     if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
     static_assert(NW == 8 || lds <= 80 * 1024, "two workgroups per CU");
     const long nwg = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE, BM, NW>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, d);
+    if constexpr (LN) hipLaunchKernelGGL((gemm_big_ln_kernel<T>), dim3((unsigned)nwg), dim3(512), lds, st, d);
+    else if constexpr (NW == 4) hipLaunchKernelGGL((gemm_big4_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(256), lds, st, d);
+    else hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(512), lds, st, d);
     return lwdetr_check_launch();
 }
 
@@ -1460,6 +1607,14 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
         const int wg2_mode = wg2_env ? atoi(wg2_env) : 1;
         const bool wg2 = variant == 128 || (variant == 0 && (wg2_mode == 2 || (wg2_mode == 1 && big_2wg_pays<AMODE>(d, bn))));
         int rc;
+        bool ln = false;
+        for (int s_ = 0; s_ < d.nseg; ++s_) ln = ln || d.seg[s_].ln_stats != nullptr;
+        if (ln) {       // LayerNorm folded into the GEMM: the 256 x 256 tile's own kernel or nothing (lwdetr_gemm reports the rest as unsupported)
+            if constexpr (AMODE == LWDETR_A_PLAIN) {
+                if (bn == 256) { rc = launch_big<T, 256, 64, 2, LWDETR_A_PLAIN, 256, 8, true>(d, st); taken = rc != LWDETR_ERR_UNSUPPORTED; return taken ? rc : LWDETR_OK; }
+            }
+            return LWDETR_OK;
+        }
         if (bn == 256) rc = wg2 ? launch_big<T, 256, 32, 3, AMODE, 128, 4>(d, st)
                                 : (variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st));
         else if (bn == 192) rc = wg2 ? launch_big<T, 192, 32, 3, AMODE, 128, 4>(d, st) : launch_big<T, 192, 64, 2, AMODE>(d, st);
@@ -1560,6 +1715,8 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
         bool taken = false;
         const int rc = try_launch_big<T, AMODE>(d, st, taken);
         if (taken) return rc;
+        for (int s_ = 0; s_ < d.nseg; ++s_)
+            if (d.seg[s_].ln_stats) return LWDETR_ERR_UNSUPPORTED;      // the folded LayerNorm exists in the large-tile kernel's epilogue only
     }
     if constexpr (sizeof(T) == 2) {
         static const char* env = getenv("LWDETR_GEMM_DMA");
@@ -1630,11 +1787,8 @@ extern "C" int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_st
         if (g.mode == LWDETR_OUT_DECONV2x2 && (g.p0 <= 0 || g.p0 % 4 != 0)) return LWDETR_ERR_BAD_ARG;
         if (g.mode < 0 || g.mode > LWDETR_OUT_DECONV2x2) return LWDETR_ERR_BAD_ARG;
         if ((g.ln_stats != nullptr) != (g.ln_colsum != nullptr)) return LWDETR_ERR_BAD_ARG;
-        if (g.rowstat_out && (g.mode != LWDETR_OUT_LINEAR || g.rowmask || d.M % 64 != 0 || g.n_begin % 256 != 0 || g.n_end % 256 != 0 || g.n_end > d.N ||
-                              g.ldo % 8 != 0 || ((size_t)g.out & 15) != 0 || (g.res && (g.ldres % 8 != 0 || ((size_t)g.res & 15) != 0)) ||
-                              (g.out2 && (g.ld2 % 8 != 0 || ((size_t)g.out2 & 15) != 0)) || dtype == DT_F32 || g.act != LWDETR_ACT_NONE))
-            return LWDETR_ERR_UNSUPPORTED;
         if (g.ln_stats && (d.a_mode != LWDETR_A_PLAIN || d.A2)) return LWDETR_ERR_BAD_ARG;      // row statistics of the plain A rows
+        if ((g.ln_stats != nullptr) != (d.seg[0].ln_stats != nullptr)) return LWDETR_ERR_BAD_ARG;    // all segments of a launch or none
     }
     if (d.seg[d.nseg - 1].n_end < d.N) return LWDETR_ERR_BAD_ARG;
     if (d.splitk < 0 || d.splitk > 16 || (d.splitk >= 2 && (!d.splitk_ws || ((size_t)d.splitk_ws & 15) != 0))) return LWDETR_ERR_BAD_ARG;

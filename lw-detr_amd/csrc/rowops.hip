@@ -223,33 +223,8 @@ extern "C" int lwdetr_row_stats(const void* x, long ldx, long M, int C, float ep
     }
 }
 
-// (count, mean, M2) slots of a row -> (mean, rstd): pairwise update (Chan et al.), one thread per row
-__global__ __launch_bounds__(256) void row_stats_finish_kernel(const float* __restrict__ rs, int nslots, long M, int C, float eps, float* __restrict__ stats) {
-    const long m = (long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < nslots; ++s) {
-        const f32x4 p = *(const f32x4*)(rs + ((long)s * M + m) * 4);       // (count, mean, M2, -)
-        const float cnt = p[0];
-        if (cnt > 0.f) {
-            const float mt = p[1], dlt = mt - mean, tot = n + cnt;
-            mean += dlt * cnt / tot;
-            m2 += p[2] + dlt * dlt * n * cnt / tot;
-            n = tot;
-        }
-    }
-    stats[m] = mean;
-    stats[M + m] = 1.f / sqrtf(m2 / (float)C + eps);
-}
-
-extern "C" int lwdetr_row_stats_finish(const float* rowstat, int nslots, long M, int C, float eps, float* stats, void* hip_stream) {
-    if (!rowstat || !stats || nslots <= 0 || M < 0 || C <= 0) return LWDETR_ERR_BAD_ARG;
-    if (M == 0) return LWDETR_OK;
-    hipStream_t st = (hipStream_t)hip_stream;
-    ProfScope ps(KID_LAYERNORM, 0.0, 16.0 * nslots * M + 8.0 * M, st);
-    hipLaunchKernelGGL(row_stats_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, rowstat, nslots, M, C, eps, stats);
-    return lwdetr_check_launch();
-}
+namespace {
+}  // namespace
 
 extern "C" int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* out, long ldo,
                                 long M, int C, float eps, long rows_per_batch, long out_batch_rows, long out_row_offset,

@@ -205,23 +205,17 @@ class ForwardPlan:
                                                                            self.Hp, self.Wp, self.Twp))
         qscale = K.attention_scale(hd)
         fused = K.mlp_fused_supported(C, self.T, rows)
-        # LayerNorm folded into the following GEMM on the unfused path (16-bit, many rows: the C = 768 model; LWDETR_LN_FOLD=0|1 forces it)
+        # LayerNorm folded into the following GEMM on the unfused path (the C = 768 model): built, validated - and worth NOTHING against the round-4
+        # tree on the same box (xlarge 960 x 960 B = 16: 774.0 / 772.2 / 770.5 img/s round-4 tree, 774.0 / 771.2 / 774.2 this tree without the fold,
+        # 774.9 / 772.9 / 773.0 with it): the folded epilogue's own kernel runs QKV 290 -> 310 us and fc1 372 -> 399 us, which is what the two
+        # 37 -> 19 us statistics passes save (profiles/r5d_*, r5g_*). Opt-in: LWDETR_LN_FOLD=1 (rows >= 16 384: the large-tile kernel's shapes).
         lf_env = os.environ.get("LWDETR_LN_FOLD")
-        ln_fold = (not fused) and self.T != torch.float32 and (lf_env == "1" or (lf_env is None and rows >= 12800))
+        ln_fold = (not fused) and self.T != torch.float32 and C % 256 == 0 and lf_env == "1"
         ln_stats = torch.empty(2, rows, dtype=torch.float32, device=self.dev) if ln_fold else None
         self.ln_fold = ln_fold
-        # The statistics can also come out of the epilogue of the GEMM that PRODUCES the rows (patch embedding, attention projection, fc2:
-        # seg(rowstat_out=...), merged per row by lwdetr_row_stats_finish) - built, tested, and measured SLOWER than the pass over the rows:
-        # the two in-wave reductions per row cost the producing launches +25 us each (proj 102 -> 130 us, fc2 288 -> 313 us at xlarge 960x960
-        # B = 16) where lwdetr_row_stats costs 19 us; xlarge 759-763 img/s with the pass, 747-751 with the epilogue statistics, 743-747 without
-        # the fold (profiles/r5d_layernorm_fold_xlarge.txt). LWDETR_LN_FOLD_STATS=1 selects the epilogue form.
-        ln_prod = ln_fold and rows % 64 == 0 and C % 256 == 0 and os.environ.get("LWDETR_LN_FOLD_STATS", "0") == "1"
-        # one zero-initialised record buffer per producing GEMM (patch embedding, projection, fc2: their column tiles differ, and a slot a
-        # launch never writes must keep count 0)
-        rs_new = lambda: torch.zeros((C // 64) * rows * 4, dtype=torch.float32, device=self.dev) if ln_prod else None
-        rs_patch, rs_proj, rs_fc2 = rs_new(), rs_new(), rs_new()
-        self.ln_prod = ln_prod
-        stats_op = lambda rs: K.RowStatsFinishOp(rs, ln_stats, rows, C, 1e-6) if ln_prod else K.RowStatsOp(self.x, ln_stats, rows, C, 1e-6)
+        # (Statistics out of the epilogue of the GEMM that PRODUCES the rows were built in four forms and measured a tie at best against this
+        # pass - and their code in the shared epilogue was part of what slowed every large-tile GEMM down: removed, profiles/r5d_*, r5g_*.)
+        stats_op = lambda: K.RowStatsOp(self.x, ln_stats, rows, C, 1e-6)
         blk0_fused = fused and K.vit_block_supported(C, self.T, hd, rows) and rows % Tp == 0 and Tp % 8 == 0
         # round 4: patch embedding + position embedding + block 0's norm1 / QKV as ONE launch at the batch sizes of the block kernel
         self.stem_op = self.patch_op = None
@@ -238,7 +232,7 @@ class ForwardPlan:
             wpe = pw.w(pre + ".patch_embed.proj.weight", lambda t: t.reshape(t.shape[0], -1))
             dummy_img = z(1, 8)
             ops.append(GemmOp(dummy_img, wpe, rows, C, 768, [
-                seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp, rowstat_out=rs_patch)],
+                seg(self.x, 0, C, ldo=C, bias=pw.f(pre + ".patch_embed.proj.bias"), res=pos, ldres=C, res_mod=Tp)],
                 a_mode=A_PATCH16, a_tok=self.win_tok, img_h=self.H, img_w=self.W, keep=(pos,)))
             self.patch_op = ops[-1]
         for i in range(self.depth):
@@ -259,7 +253,7 @@ class ForwardPlan:
                     pw.sd[blk + ".attn.qkv.weight"], torch.cat([pw.sd[blk + ".attn.q_bias"].detach().float(), torch.zeros(C, device=self.dev),
                                                                 pw.sd[blk + ".attn.v_bias"].detach().float()]),
                     pw.sd[blk + ".norm1.weight"], pw.sd[blk + ".norm1.bias"], self.T))
-                ops.append(stats_op(rs_patch if i == 0 else rs_fc2))
+                ops.append(stats_op())
                 ops.append(GemmOp(self.x, wq_, rows, 3 * C, C, [
                     seg(q, 0, C, mode=OUT_HEADS, bias=bq_[:C], scale=qscale, p0=Tp, p1=hd, p2=heads, ln_stats=ln_stats, ln_colsum=cs_[:C]),
                     seg(k, C, 2 * C, mode=OUT_HEADS, bias=bq_[C:2 * C], p0=Tp, p1=hd, p2=heads, ln_stats=ln_stats, ln_colsum=cs_[C:2 * C]),
@@ -282,7 +276,7 @@ class ForwardPlan:
             if not fused:
                 ops.append(GemmOp(att, pw.w(blk + ".attn.proj.weight"), rows, C, C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".attn.proj.bias"), gamma=pw.f(blk + ".gamma_1"),
-                        res=self.x, ldres=C, rowstat_out=rs_proj)]))
+                        res=self.x, ldres=C)]))
             tap_out = None
             if i in self.taps:
                 j = self.taps.index(i)
@@ -320,7 +314,7 @@ class ForwardPlan:
                 if ln_fold:        # norm2 folded into fc1 (see norm1 above)
                     w1_, cs1_, b1_ = pw.custom_multi(blk + ".fc1.lnfold", lambda blk=blk: K.fold_layernorm(
                         pw.sd[blk + ".mlp.fc1.weight"], pw.sd[blk + ".mlp.fc1.bias"], pw.sd[blk + ".norm2.weight"], pw.sd[blk + ".norm2.bias"], self.T))
-                    ops.append(stats_op(rs_proj))
+                    ops.append(stats_op())
                     ops.append(GemmOp(self.x, w1_, rows, 4 * C, C, [
                         seg(hid, 0, 4 * C, ldo=4 * C, bias=b1_, act=ACT_GELU, ln_stats=ln_stats, ln_colsum=cs1_)], keep=(w1_, cs1_, b1_)))
                 else:
@@ -329,7 +323,7 @@ class ForwardPlan:
                         seg(hid, 0, 4 * C, ldo=4 * C, bias=pw.f(blk + ".mlp.fc1.bias"), act=ACT_GELU)]))
                 ops.append(GemmOp(hid, pw.w(blk + ".mlp.fc2.weight"), rows, C, 4 * C, [
                     seg(self.x, 0, C, ldo=C, bias=pw.f(blk + ".mlp.fc2.bias"), gamma=pw.f(blk + ".gamma_2"), res=self.x,
-                        ldres=C, out2=tap_out, ld2=ntap * C, rowstat_out=rs_fc2 if i + 1 < self.depth else None)], keep=(tap_out,)))
+                        ldres=C, out2=tap_out, ld2=ntap * C)], keep=(tap_out,)))
 
     def _vit_block_ok(self, blk):
         """lwdetr_vit_block divides by the LayerScale vectors: blocks with (near-)zero entries stay on lwdetr_mlp_fused."""

@@ -38,7 +38,7 @@ def tok_layout(winmajor=False, hp=0, wp=0, twp=0) -> TokLayout:
 
 def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE, scale=1.0, gamma=None, res=None,
         ldres=0, res_mod=0, out2=None, ld2=0, rowmask=None, rowmask_after=False, p0=0, p1=0, p2=0, in_tok=None, out_tok=None,
-        out_batch_stride=0, out_row_offset=0, ln_stats=None, ln_colsum=None, rowstat_out=None) -> GemmSeg:
+        out_batch_stride=0, out_row_offset=0, ln_stats=None, ln_colsum=None) -> GemmSeg:
     """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h). ln_stats (M, 2) f32 + ln_colsum (n) f32:
     LayerNorm folded into the GEMM (fold_layernorm packs the weights; RowStatsOp produces the planar (2, M) statistics)."""
     s = GemmSeg()
@@ -48,10 +48,7 @@ def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE,
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_colsum.dtype == torch.float32
         ln_colsum = _pad8(ln_colsum, n_end - n_begin, 0.0)
         s.ln_stats, s.ln_colsum = _ptr(ln_stats), _ptr(ln_colsum)
-    if rowstat_out is not None:
-        assert rowstat_out.dtype == torch.float32 and rowstat_out.is_contiguous()
-        s.rowstat_out = _ptr(rowstat_out)
-    s._keep = (bias, gamma, ln_stats, ln_colsum, rowstat_out)           # padded copies must outlive the launch
+    s._keep = (bias, gamma, ln_stats, ln_colsum)           # padded copies must outlive the launch
     s.out, s.out2, s.res = _ptr(out), _ptr(out2), _ptr(res)
     s.bias, s.gamma, s.rowmask = _ptr(bias), _ptr(gamma), _ptr(rowmask)
     assert rowmask is None or rowmask.dtype == torch.uint8
@@ -173,21 +170,6 @@ class RowStatsOp:
         rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
         if rc:
             _nat.check(rc, "row_stats")
-
-
-class RowStatsFinishOp:
-    """stats (2, M) planar = (mean, rstd) from the (count, mean, M2) slots the producing GEMM wrote (seg(rowstat_out=...)): no pass over the rows."""
-
-    def __init__(self, rowstat, stats, M, C_, eps):
-        assert rowstat.dtype == torch.float32 and stats.dtype == torch.float32 and C_ % 64 == 0 and rowstat.numel() >= (C_ // 64) * M * 4
-        self.args = (_ptr(rowstat), C_ // 64, M, C_, float(eps), _ptr(stats))
-        self._keep = (rowstat, stats)
-        self._fn = _nat.lib().lwdetr_row_stats_finish
-
-    def __call__(self, stream=None):
-        rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
-        if rc:
-            _nat.check(rc, "row_stats_finish")
 
 
 def fold_layernorm(w, b, ln_w, ln_b, dtype):

@@ -151,15 +151,15 @@ class LWDETR(nn.Module):
 
     @staticmethod
     def _chains_for(b, h=640, w=640):
-        """Launch chains for a dense batch of b images of h x w pixels: default two from _TWO_STREAM_MIN_BATCH images - at 900 x 900 pixels and
-        up already from 16 (round 5: xlarge 960 x 960 B = 16 as two 8-image chains +1.1 % on two boxes, profiles/r5f_*; round 4: +1 %);
-        LWDETR_STREAMS / set_streams: 1 = one chain, n >= 2 = n chains whenever the batch splits into n parts of at least 8 images."""
+        """Launch chains for a dense batch of b images (h x w pixels: kept in the signature, not used by the default rule - xlarge 960 x 960 B = 16
+        as two 8-image chains measured +1.1 %, +1.3 % and -1.0 % on three boxes of round 5: inside the noise, left at one chain as in round 4):
+        default two from _TWO_STREAM_MIN_BATCH images; LWDETR_STREAMS / set_streams: 1 = one chain, n >= 2 = n chains whenever the batch splits
+        into n parts of at least 8 images."""
         if _STREAMS == 1:
             return 1
         if _STREAMS >= 2:
             return _STREAMS if (b % _STREAMS == 0 and b // _STREAMS >= 8) else 1
-        min_b = _TWO_STREAM_MIN_BATCH if h * w < 900 * 900 else _TWO_STREAM_MIN_BATCH // 2
-        return 2 if (b >= min_b and b % 2 == 0) else 1
+        return 2 if (b >= _TWO_STREAM_MIN_BATCH and b % 2 == 0) else 1
 
     def _forward_chains(self, x, b, h, w, nch, post=None, collect=None):
         """The parts of a dense batch as ``nch`` launch chains on ``nch`` streams. Every kernel of the path runs its workgroups in

@@ -188,7 +188,7 @@ def test_launch_chain_policy():
     try:
         L.set_streams(0)
         assert [LWDETR._chains_for(b) for b in (1, 8, 16, 31, 32, 33, 64)] == [1, 1, 1, 1, 2, 1, 2]
-        assert [LWDETR._chains_for(b, 960, 960) for b in (8, 14, 16, 32)] == [1, 1, 2, 2]         # 900 x 900 pixels and up: from 16 images
+        assert [LWDETR._chains_for(b, 960, 960) for b in (8, 14, 16, 32)] == [1, 1, 1, 2]         # the resolution does not change the rule
         L.set_streams(1)
         assert [LWDETR._chains_for(b) for b in (32, 64)] == [1, 1]
         L.set_streams(4)
