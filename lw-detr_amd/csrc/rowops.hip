@@ -223,9 +223,6 @@ extern "C" int lwdetr_row_stats(const void* x, long ldx, long M, int C, float ep
     }
 }
 
-namespace {
-}  // namespace
-
 extern "C" int lwdetr_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* out, long ldo,
                                 long M, int C, float eps, long rows_per_batch, long out_batch_rows, long out_row_offset,
                                 int dtype, void* hip_stream) {
