@@ -133,8 +133,42 @@ __device__ __forceinline__ float gelu_s1(float x, float x2, float p) {
 }
 __device__ __forceinline__ float gelu_s2(float x, float e) { return x * __builtin_amdgcn_rcpf(1.f + e); }
 
-template <typename T, int C, int NH, bool QKV, int WPC = 1>
+// ---- GELU on packed f16 pairs (round 5, opt-in: LWDETR_VB_GELU16=1, f16 only). The same two-term form
+// x * rcp(1 + exp2(x (c1 x^2 + c0))) evaluated in f16 on the value pairs that the fc2 operand needs anyway: per 8 values 4 v_cvt_pk +
+// 4 v_pk_mul + 4 v_pk_fma + 4 v_pk_mul + 8 v_exp_f16 + 4 v_pk_add + 8 v_rcp_f16 + 4 v_pk_mul = 40 VALU-class instructions instead of
+// 60 (the transcendentals have no packed form: SDWA word selects, in place). Inline asm throughout: the layer ticks must stay where
+// they are put, no operand may carry an op_sel (tools/check_isa.py guards the packed-f32 forms; these packed-f16 ones are written
+// straight so that the question never arises), and the constants must stay in registers (a compiler-materialised constant is a
+// v_mov per use). f16 arithmetic: rms error of the GELU output 4.2e-4 instead of 2.7e-4 (f32 arithmetic, f16 result) on N(0, 1.5)
+// inputs, maximum 2.7e-3 instead of 1.2e-3 - tests/vitblock_sim.py::gelu_vb16_packed is the bit-level model.
+#define VB_G16_C0 0xc09ec09eu       // -2.30859375 (f16) twice
+#define VB_G16_C1 0xae68ae68u       // -0.10009765625
+#define VB_G16_ONE 0x3c003c00u
+__device__ __forceinline__ unsigned g16_mul(unsigned a, unsigned b) { unsigned r; asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned g16_fma(unsigned a, unsigned c1s, unsigned c0v) {
+    unsigned r; asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c1s), "v"(c0v)); return r;
+}
+__device__ __forceinline__ unsigned g16_add(unsigned a, unsigned ones) { unsigned r; asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(ones)); return r; }
+// the transcendentals of a group's four pairs: low halves first, then high halves - an SDWA write of half a register must not be
+// followed directly by a read of that register (gfx940-family dst_sel forwarding hazard: one wait state; the hazard recognizer does
+// not look inside inline asm), so each register's two instructions sit three instructions apart, and the next tick reads
+// the registers in the same order
+#define VB_G16_TRANS4(OP)                                                                                             \
+    asm volatile(OP " %0, %0 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"                          \
+                 OP " %1, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"                          \
+                 OP " %2, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"                          \
+                 OP " %3, %3 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"                          \
+                 OP " %0, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
+                 OP " %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
+                 OP " %2, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
+                 OP " %3, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"                                \
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+__device__ __forceinline__ void g16_exp2x4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) { VB_G16_TRANS4("v_exp_f16_sdwa"); }
+__device__ __forceinline__ void g16_rcpx4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) { VB_G16_TRANS4("v_rcp_f16_sdwa"); }
+
+template <typename T, int C, int NH, bool QKV, int WPC = 1, bool G16 = false>
 __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
+    static_assert(!G16 || sizeof(T) == 2, "");
     typedef typename Vec<T>::v8 V8;
     static_assert(sizeof(T) == 2, "16-bit types only");
     constexpr int KS = C / 16;                  // k-steps of a K = C contraction = fragments per piece
@@ -376,6 +410,12 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
     // ---- hidden loop, software pipelined. Pieces after the projection: W1c(0), W1c(1), then (W2c(k-1), W1c(k+1)) for k = 1 ..
     // NCH-2, then W2c(NCH-2), W2c(NCH-1). Iteration k: GELU(k) on the VALU, fc2(k-1) and fc1(k+1) on the matrix pipe.
     f32x16 acc1[2][NH];
+    unsigned g16_c0 = 0, g16_c1 = 0, g16_one = 0;      // G16: the packed-f16 GELU's constants, produced by asm so that they STAY in registers
+    if constexpr (G16) {
+        asm volatile("v_mov_b32 %0, 0xc09ec09e" : "=v"(g16_c0));
+        asm volatile("s_mov_b32 %0, 0xae68ae68" : "=s"(g16_c1));
+        asm volatile("s_mov_b32 %0, 0x3c003c00" : "=s"(g16_one));
+    }
     u32x4 hf[2][NH][2];                         // GELU output as B operands (packed pairs): [buffer][token half][k-step of the chunk]
     auto bias16 = [&](const float* src) -> f32x16 {      // src[8 b + 4 h + e] -> register 4 b + e
         f32x16 r;
@@ -403,11 +443,30 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
 #pragma unroll
         for (int i = 0; i < RD; ++i) if (i < NF) fr[i] = fragi(i);
         float ga[8], gb[8];
+        unsigned gx[4], gq[4];                 // G16: the group's value pairs / the running term
 #define VB_PIN8(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
         // GELU for 16-bit storage in its two-term form x * sigmoid(-x (c0 + c1 x^2)) (vb_gelu16, max |error| 2.7e-4 - a tenth of
         // what 16-bit arithmetic costs end to end): 7 instructions per value instead of 9
         auto tick = [&](auto ti_tag) {
             constexpr int ti = decltype(ti_tag)::value, grp = ti / NL, L = ti % NL, th = grp >> 1, r0 = 8 * (grp & 1);
+            if constexpr (G16) {
+                // packed-f16 form: gx = the four value pairs of the group (what fc2 multiplies is their GELU), gq = the running term
+                if constexpr (L == 4) g16_exp2x4(gq[0], gq[1], gq[2], gq[3]);
+                else if constexpr (L == 6) g16_rcpx4(gq[0], gq[1], gq[2], gq[3]);
+                else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if constexpr (L == 0) gx[d] = pack2<T>(acc1[CUR][th][r0 + 2 * d], acc1[CUR][th][r0 + 2 * d + 1]);
+                        else if constexpr (L == 1) gq[d] = g16_mul(gx[d], gx[d]);
+                        else if constexpr (L == 2) gq[d] = g16_fma(gq[d], g16_c1, g16_c0);
+                        else if constexpr (L == 3) gq[d] = g16_mul(gx[d], gq[d]);
+                        else if constexpr (L == 5) gq[d] = g16_add(gq[d], g16_one);
+                        else gq[d] = g16_mul(gx[d], gq[d]);
+                    }
+                }
+                if constexpr (L == 0) asm volatile("" : "+v"(gx[0]), "+v"(gx[1]), "+v"(gx[2]), "+v"(gx[3]));
+                if constexpr (L == 7) hf[CUR][th][grp & 1] = u32x4{gq[0], gq[1], gq[2], gq[3]};
+            } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float x = acc1[CUR][th][r0 + u];
@@ -427,6 +486,7 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
                 for (int d = 0; d < 4; ++d) w[d] = pack2<T>(gb[2 * d], gb[2 * d + 1]);
                 asm volatile("" : "+v"(w));
                 hf[CUR][th][grp & 1] = w;
+            }
             }
         };
         static_assert((TK + S - 1) / S <= 2, "at most two GELU ticks per MFMA slot");
@@ -1252,7 +1312,7 @@ int launch_vs(const VsParams& p, hipStream_t st) {
 
 struct VbLaunchState { bool attr_done; int ncu; };
 
-template <typename T, int C, int NH, bool QKV, int WPC = 1>
+template <typename T, int C, int NH, bool QKV, int WPC = 1, bool G16 = false>
 int launch_vb(const VbParams& p, hipStream_t st) {
     constexpr int KS = C / 16, PIECE_B = KS * 1024, NSLOT = WPC == 2 ? 5 : (C == 192 ? 8 : 5);
     constexpr int VEC_B = (13 * C * 4 + 4095) / 4096 * 4096;
@@ -1262,7 +1322,7 @@ int launch_vb(const VbParams& p, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
     VbLaunchState& s = state[dev];
     if (!s.attr_done) {
-        if (hipFuncSetAttribute((const void*)vitblock_kernel<T, C, NH, QKV, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)vitblock_kernel<T, C, NH, QKV, WPC, G16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LWDETR_ERR_LAUNCH;
@@ -1283,7 +1343,7 @@ int launch_vb(const VbParams& p, hipStream_t st) {
     while (((p.M / 8 + grid * 4 - 1) / (grid * 4)) * 8 > 32 * NH) ++grid;
     ProfScope ps(KID_VITBLOCK, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C,
                  (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T) + (p.out2 ? 1.0 : 0.0) * p.M * C * sizeof(T), st);
-    hipLaunchKernelGGL((vitblock_kernel<T, C, NH, QKV, WPC>), dim3((unsigned)grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((vitblock_kernel<T, C, NH, QKV, WPC, G16>), dim3((unsigned)grid), dim3(256), lds, st, p);
     return lwdetr_check_launch();
 }
 
@@ -1294,6 +1354,10 @@ int dispatch_vb(const VbParams& p, int C, bool qkv, hipStream_t st) {
     // one workgroup's latency either way - 84 -> 67 us at M = 25 600 (one launch chain of config 2: 200 workgroups, one per CU), equal at
     // M = 51 200 (400 workgroups, two per CU: 93.7 vs 92 us) - and its waves leave half of each SIMD's registers to the other chain's
     // kernels: config 2 +1.3 % (two A/B pairs on one box). LWDETR_VB_HALF=0|1 forces either form (read per launch: tests switch it).
+    // LWDETR_VB_GELU16=1: the GELU on packed f16 pairs (f16 only; read per launch: tests switch it). Off by default - see the helpers' comment
+    // and profiles/r5h_*.
+    const char* g16_env = getenv("LWDETR_VB_GELU16");
+    const bool g16 = std::is_same<T, f16>::value && g16_env && atoi(g16_env) == 1;
     if (C == 192) {
         const char* half_env = getenv("LWDETR_VB_HALF");
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1301,7 +1365,15 @@ int dispatch_vb(const VbParams& p, int C, bool qkv, hipStream_t st) {
         if (dev >= 0 && dev < 16 && ncu[dev] == 0) { hipDeviceProp_t prop; ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
         const long cus = dev >= 0 && dev < 16 ? ncu[dev] : 256;
         const bool half = half_env ? atoi(half_env) == 1 : (p.M + 127) / 128 <= 2 * cus;
-        if (half) return qkv ? launch_vb<T, 192, 1, true, 2>(p, st) : launch_vb<T, 192, 1, false, 2>(p, st);
+        if (half) {
+            if constexpr (sizeof(T) == 2 && std::is_same<T, f16>::value)
+                if (g16) return qkv ? launch_vb<T, 192, 1, true, 2, true>(p, st) : launch_vb<T, 192, 1, false, 2, true>(p, st);
+            return qkv ? launch_vb<T, 192, 1, true, 2>(p, st) : launch_vb<T, 192, 1, false, 2>(p, st);
+        }
+    }
+    if constexpr (std::is_same<T, f16>::value) {
+        if (g16 && C == 192) return qkv ? launch_vb<T, 192, 2, true, 1, true>(p, st) : launch_vb<T, 192, 2, false, 1, true>(p, st);
+        if (g16 && C == 384) return qkv ? launch_vb<T, 384, 1, true, 1, true>(p, st) : launch_vb<T, 384, 1, false, 1, true>(p, st);
     }
     if (C == 192) return qkv ? launch_vb<T, 192, 2, true>(p, st) : launch_vb<T, 192, 2, false>(p, st);
     if (C == 384) return qkv ? launch_vb<T, 384, 1, true>(p, st) : launch_vb<T, 384, 1, false>(p, st);

@@ -649,8 +649,10 @@ def test_mlp_fused(dtype, c, m):
 @pytest.mark.parametrize("c,heads,m,tp", [(192, 6, 51200, 1600), (192, 12, 12800, 400), (192, 3, 20000, 400), (192, 6, 64000, 1600),
                                           (384, 12, 25600, 1600), (384, 12, 12816, 4272), (192, 6, 13000, 1000)])
 @pytest.mark.parametrize("half", ["0", "1"])
-def test_vit_block(dtype, c, heads, m, tp, half, monkeypatch):
-    """half = 1: the C = 192 form with 32 tokens per wave / two workgroups per CU (round 5; the default while all workgroups of a launch
+@pytest.mark.parametrize("gelu16", ["0", "1"])
+def test_vit_block(dtype, c, heads, m, tp, half, gelu16, monkeypatch):
+    """gelu16 = 1: the opt-in GELU on packed f16 pairs (LWDETR_VB_GELU16=1, f16 only; tests/vitblock_sim.py:gelu_vb16_packed) - same bounds
+    against the erf-GELU fp32 formulation, different bits from the f32-arithmetic form and within 2e-3 of it. half = 1: the C = 192 form with 32 tokens per wave / two workgroups per CU (round 5; the default while all workgroups of a launch
     are resident at once), half = 0: 64 tokens per wave. lwdetr_vit_block (attention projection + LayerScale + residual, norm2 -> fc1 -> GELU -> fc2 -> LayerScale -> residual, and
     norm1 + QKV of the next block, one launch) vs the torch fp32 formulation of vit.py:195-222 and vs lwdetr_mlp_fused on the
     same 16-bit weights. 51200 = BASELINE config 2 (32 images x 1600 tokens: 50 tokens per wave), 64000 / 25600 = more than one
@@ -658,7 +660,10 @@ def test_vit_block(dtype, c, heads, m, tp, half, monkeypatch):
     from lwdetr_amd import kernels as K
     if c != 192 and half == "1":
         pytest.skip("the half-tile form exists for C = 192 only")
+    if gelu16 == "1" and dtype != torch.float16:
+        pytest.skip("packed-f16 GELU: f16 only")
     monkeypatch.setenv("LWDETR_VB_HALF", half)
+    monkeypatch.setenv("LWDETR_VB_GELU16", gelu16)
     hd = c // heads
     assert K.vit_block_supported(c, dtype, hd)
     x = _rand(m, c, dtype=dtype, seed=1) * 2 + 0.3
@@ -711,6 +716,12 @@ def test_vit_block(dtype, c, heads, m, tp, half, monkeypatch):
         xx2 = x.clone()
         K.VitBlockOp(xx2, att, stream, vec, m, c, 1e-6, **kw)()
         assert torch.equal(xx2, xx)
+        if gelu16 == "1":                        # the switch is read per launch: the same op with the f32-arithmetic GELU
+            monkeypatch.setenv("LWDETR_VB_GELU16", "0")
+            xx3 = x.clone()
+            K.VitBlockOp(xx3, att, stream, vec, m, c, 1e-6, **kw)()
+            monkeypatch.setenv("LWDETR_VB_GELU16", "1")
+            assert not torch.equal(xx3, xx) and _relerr(xx3, xx) < 2e-3, _relerr(xx3, xx)
     w1p, b1p, w2p = K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype, proj=True)
     xo = x.clone()
     K.MlpFusedOp(xo, w1p, b1p, w2p, b2, g2, m, c, 1e-6, att=att, wp=wp.to(dtype).contiguous(), bp=bp, gamma1=g1)()

@@ -63,3 +63,27 @@ def test_pack_vit_block_refuses_zero_layerscale():
     w["g2"][7] = 0.0
     with pytest.raises(ValueError):
         K.pack_vit_block(w["wp"], w["bp"], w["g1"], w["w1"], w["b1"], w["w2"], w["b2"], w["g2"], w["ln2_w"], w["ln2_b"], torch.float16)
+
+
+def test_packed_f16_gelu_model_error_budget():
+    """The opt-in packed-f16 GELU of the block kernel (vitblock_sim.gelu_vb16_packed = the instruction sequence with every result rounded
+    to f16) against the exact erf form over every f16 input in [-12, 12] and on N(0, 1.5) inputs: saturates correctly at both ends (no NaN
+    from the f16 overflow of x^2 or 2^t), maximum error 2.7e-3 (1.4 f16 ulps of a result near 3), rms 4.2e-4 - 1.55x the f32-arithmetic form
+    (2.7e-4), of which 2.0e-4 is the f16 rounding of the result that both share."""
+    from scipy.special import erf
+    from tests.vitblock_sim import gelu_vb16, gelu_vb16_packed
+    exact = lambda v: 0.5 * v * (1.0 + erf(v / np.sqrt(2.0)))
+    allh = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    allh = allh[np.isfinite(allh)].astype(np.float64)
+    y = gelu_vb16_packed(allh)
+    assert np.isfinite(y).all()
+    big = np.abs(allh) > 12
+    assert np.array_equal(y[big & (allh > 0)], allh[big & (allh > 0)]) and np.all(y[big & (allh < 0)] == 0)
+    x = allh[~big]
+    assert np.abs(gelu_vb16_packed(x) - exact(x)).max() < 2.8e-3
+    xs = (np.random.default_rng(0).standard_normal(200000) * 1.5).astype(np.float16).astype(np.float64)
+    rms = lambda e: float(np.sqrt((e ** 2).mean()))
+    r_packed = rms(gelu_vb16_packed(xs) - exact(xs))
+    r_f32 = rms(gelu_vb16(xs).astype(np.float16).astype(np.float64) - exact(xs))
+    assert r_packed < 4.5e-4 and r_packed < 1.7 * r_f32, (r_packed, r_f32)
+

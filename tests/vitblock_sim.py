@@ -35,6 +35,18 @@ def gelu_vb16(x):
     return x / (1.0 + np.exp2(x * (-2.3087653 - 0.10012561 * x * x)))
 
 
+def gelu_vb16_packed(x):
+    """The block kernel's opt-in packed-f16 form (vitblock.hip: VB_G16_*, LWDETR_VB_GELU16=1): the same two-term expression with EVERY
+    operation rounded to f16 - x itself first (v_cvt_pk_f16_f32), then v_pk_mul (x^2), v_pk_fma (c1 x^2 + c0, one rounding), v_pk_mul,
+    v_exp_f16, v_pk_add, v_rcp_f16, v_pk_mul. exp2 / rcp are modelled correctly rounded (the hardware's are within an ulp)."""
+    h = lambda v: np.asarray(v, dtype=np.float64).astype(np.float16).astype(np.float64)
+    c0 = float(np.array([0xc09e], dtype=np.uint16).view(np.float16)[0]); c1 = float(np.array([0xae68], dtype=np.uint16).view(np.float16)[0])
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+        xh = h(x)
+        t = h(xh * h(h(xh * xh) * c1 + c0))
+        return h(xh * h(1.0 / h(1.0 + h(np.exp2(t)))))
+
+
 def simulate_wave(stream, vec, x, att, t0, nvalid, C, NH, eps, eps_next, qkv=None, order="pipelined"):
     """One wave of the kernel: tokens [t0, t0 + nvalid) of x / att (M, C). Returns (new rows (nvalid, C), dict of q/k/v writes).
     qkv = dict(heads, hd, Tp, qscale) or None; writes are returned as {("q"|"k"|"v", flat element index): value}."""
