@@ -133,7 +133,7 @@ __device__ __forceinline__ float gelu_s1(float x, float x2, float p) {
 }
 __device__ __forceinline__ float gelu_s2(float x, float e) { return x * __builtin_amdgcn_rcpf(1.f + e); }
 
-// ---- GELU on packed f16 pairs (round 5, opt-in: LWDETR_VB_GELU16=1, f16 only). The same two-term form
+// ---- GELU on packed f16 pairs (round 5; the f16 default, LWDETR_VB_GELU16=0 turns it off). The same two-term form
 // x * rcp(1 + exp2(x (c1 x^2 + c0))) evaluated in f16 on the value pairs that the fc2 operand needs anyway: per 8 values 4 v_cvt_pk +
 // 4 v_pk_mul + 4 v_pk_fma + 4 v_pk_mul + 8 v_exp_f16 + 4 v_pk_add + 8 v_rcp_f16 + 4 v_pk_mul = 40 VALU-class instructions instead of
 // 60 (the transcendentals have no packed form: SDWA word selects, in place). Inline asm throughout: the layer ticks must stay where
@@ -1354,10 +1354,11 @@ int dispatch_vb(const VbParams& p, int C, bool qkv, hipStream_t st) {
     // one workgroup's latency either way - 84 -> 67 us at M = 25 600 (one launch chain of config 2: 200 workgroups, one per CU), equal at
     // M = 51 200 (400 workgroups, two per CU: 93.7 vs 92 us) - and its waves leave half of each SIMD's registers to the other chain's
     // kernels: config 2 +1.3 % (two A/B pairs on one box). LWDETR_VB_HALF=0|1 forces either form (read per launch: tests switch it).
-    // LWDETR_VB_GELU16=1: the GELU on packed f16 pairs (f16 only; read per launch: tests switch it). Off by default - see the helpers' comment
-    // and profiles/r5h_*.
+    // f16: the GELU on packed f16 pairs (the helpers' comment above; profiles/r5h_block_kernel_packed_f16_gelu.txt: launch -1.5 ... -2.5 %,
+    // config 2 / large +0.8 / +0.9 %, the model's mean 16-bit error +0.9 %). LWDETR_VB_GELU16=0 restores the f32-arithmetic form (read per
+    // launch: tests switch it); bf16 has no packed arithmetic and keeps it.
     const char* g16_env = getenv("LWDETR_VB_GELU16");
-    const bool g16 = std::is_same<T, f16>::value && g16_env && atoi(g16_env) == 1;
+    const bool g16 = std::is_same<T, f16>::value && (g16_env ? atoi(g16_env) == 1 : true);
     if (C == 192) {
         const char* half_env = getenv("LWDETR_VB_HALF");
         int dev = 0; (void)hipGetDevice(&dev);
