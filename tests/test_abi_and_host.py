@@ -180,6 +180,32 @@ def test_packed_weight_cache_token_sees_every_way_weights_can_change():
         m._packed_weights()
 
 
+def test_layernorm_fold_is_the_layernorm_then_linear():
+    """kernels.fold_layernorm (host side of the opt-in LayerNorm fold, vit.py:199 / :217 in front of the QKV / fc1 Linear): with the weights it
+    returns, rstd (x . w'_n - mean colsum_n) + b'_n - what lwdetr_gemm's ln_stats epilogue computes from the RAW rows - equals
+    Linear(LayerNorm(x)) on those 16-bit weights (fp64; to the f32 rounding of the column sums), and differs from the unrounded f32 weights only by their 16-bit rounding."""
+    from lwdetr_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    m, c, n, eps = 37, 256, 96, 1e-6
+    x = (torch.randn(m, c, generator=g) * 2 + 0.5).half().double()
+    w, b = torch.randn(n, c, generator=g) * c ** -0.5, torch.randn(n, generator=g) * 0.1
+    ln_w, ln_b = torch.randn(c, generator=g) * 0.2 + 1, torch.randn(c, generator=g) * 0.1
+    wq, colsum, bq = K.fold_layernorm(w, b, ln_w, ln_b, torch.float16)
+    assert wq.dtype == torch.float16 and colsum.dtype == torch.float32 and bq.dtype == torch.float32 and wq.shape == (n, c)
+    mean = x.mean(1, keepdim=True)
+    rstd = (x.var(1, unbiased=False, keepdim=True) + eps).rsqrt()
+    folded = rstd * (x @ wq.double().t() - mean * colsum.double()[None, :]) + bq.double()[None, :]
+    # the same rounded weights applied the reference's way: LayerNorm without affine, then w' and b'
+    xn = (x - mean) * rstd
+    assert (folded - (xn @ wq.double().t() + bq.double())).abs().max().item() < 1e-6      # colsum is an f32 sum: ~1e-8 x |mean|
+    # against the reference formulation with the f32 masters: only the 16-bit rounding of w' separates them
+    ref = torch.nn.functional.layer_norm(x, (c,), ln_w.double(), ln_b.double(), eps) @ w.double().t() + b.double()
+    assert (folded - ref).abs().max().item() < 2e-2 and ((folded - ref).abs().mean() / ref.abs().mean()).item() < 1e-3
+    assert torch.equal(colsum, wq.float().sum(1))                 # column sums of the ROUNDED weights: what the MFMA contraction of a constant row yields
+    wq0, _, bq0 = K.fold_layernorm(w, None, ln_w, ln_b, torch.bfloat16)
+    assert wq0.dtype == torch.bfloat16 and torch.allclose(bq0, w @ ln_b, atol=1e-6)
+
+
 def test_launch_chain_policy():
     """LWDETR._chains_for / set_streams: default two chains from 32 images (even batches only), 1 = always one, n = n chains
     whenever the parts have at least 8 images."""
