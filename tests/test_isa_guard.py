@@ -57,3 +57,42 @@ def test_guard_fails_closed(tmp_path):
     subprocess.check_call(["gcc", "-c", str(tmp_path / "host.c"), "-o", str(host)])
     r = subprocess.run([sys.executable, CHECK, str(host)], capture_output=True, text=True)
     assert r.returncode == 2 and "nothing was checked" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_packed_f16_gelu_kernels_carry_only_straight_forms():
+    """Round 5: the block kernel's GELU on packed f16 pairs (vitblock.hip, VB_G16_*; the f16 default) is inline asm written so that the
+    op_sel question of section 5d never arises. Checked on the built object: every G16 instantiation holds packed-f16 arithmetic and SDWA
+    transcendentals, none of its packed-f16 instructions carries an op_sel / op_sel_hi / neg modifier, every SDWA transcendental selects the
+    same word for source and destination and preserves the other half, and a register's two SDWA writes are never adjacent (dst_sel
+    forwarding hazard: the hazard recognizer does not look inside inline asm)."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    obj = os.path.join(ROOT, "lw-detr_amd", "csrc", "build", "vitblock.o")
+    if not os.path.exists(obj):
+        pytest.skip("library objects not built here")
+    dis = check_isa.device_disassembly(obj, "gfx950")
+    funcs, cur = {}, None
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", ln)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+        elif cur is not None and "//" in ln:
+            cur.append(ln.split("//")[0].strip())
+    g16 = {k: v for k, v in funcs.items() if "vitblock_kernel" in k and k.endswith("ELb1EEEvNS_8VbParamsE") and re.search(r"Li[12]ELb1EEEvNS_8VbParamsE$", k)}
+    assert len(g16) == 6, sorted(funcs)                     # f16 x {C = 192 x 2 tile forms, C = 384} x {with / without the next block's QKV}
+    assert all("IDF16_" in k for k in g16)                  # f16 only: bf16 has no packed arithmetic
+    for name, ins in g16.items():
+        pk = [i for i in ins if re.match(r"v_pk_(mul|fma|add)_f16\b", i)]
+        sd = [i for i in ins if re.match(r"v_(exp|rcp)_f16_sdwa\b", i)]
+        assert len(pk) >= 64 and len(sd) >= 64 and len(sd) % 8 == 0, (name, len(pk), len(sd))
+        assert not [i for i in pk if "op_sel" in i or "neg_" in i], name
+        for i in sd:
+            w = re.findall(r"(dst_sel|src0_sel):WORD_([01])", i)
+            assert len(w) == 2 and w[0][1] == w[1][1] and "dst_unused:UNUSED_PRESERVE" in i, (name, i)
+        for a, b in zip(ins, ins[1:]):
+            if a.startswith(("v_exp_f16_sdwa", "v_rcp_f16_sdwa")) and b.startswith(("v_exp_f16_sdwa", "v_rcp_f16_sdwa")):
+                assert a.split()[1] != b.split()[1], (name, a, b)          # same destination register back to back
+    # the kernels that existed before do not carry the packed-f16 forms (own instantiations: profiles/r5g_* is why)
+    old = {k: v for k, v in funcs.items() if "vitblock_kernel" in k and k not in g16}
+    assert len(old) == 12 and not any(re.match(r"v_(exp|rcp)_f16_sdwa\b", i) for v in old.values() for i in v)
