@@ -133,6 +133,15 @@ int lwdetr_row_stats(const void* x, long ldx, long M, int C, float eps, float* s
  * shape thresholds), 0 = never use the 256-row large-tile kernel, 2 = use it whenever the shape is legal for it,
  * 32 / 64 = as 2 with that stage depth. Results do not depend on it beyond f32 summation order. */
 void lwdetr_gemm_tuning(int big_mode);
+/* The persistent large-tile kernel (round 6, csrc/gemm_pt.hip: a workgroup walks its 256 x 256 tiles, the DMA ring runs on across tile boundaries,
+ * the epilogue goes straight from the accumulators to memory) serves the 16-bit plain-A launches whose segments are whole 256-column tiles of
+ * LINEAR / HEADS / HEADS_T outputs - the four Linear layers of a C = 768 ViT block (models/backbone/vit.py:123-138, :217-218). Process-wide
+ * override for tests / tuning: pt_mode -1 = default (environment LWDETR_GEMM_PT, read once; else 1), 0 = never, 1 = at the sizes where the
+ * 256-row tile pays, 2 = whenever the shape is legal; tuning: + 256 * w sets the start-skew window to w ticks of 10 ns. Results equal the
+ * large-tile kernel's up to f32 rounding of the epilogue (bias first, one scale multiplication). */
+void lwdetr_gemm_pt_tuning(int pt_mode);
+/* launches of the persistent kernel by this process so far (tests assert which kernel served a shape) */
+long lwdetr_gemm_pt_count(void);
 
 /* ---- fused softmax(QK^T)V, flash-style, MFMA ------------------------------------------------------------------- */
 typedef struct {

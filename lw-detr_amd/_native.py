@@ -88,6 +88,10 @@ def lib():
         l.lwdetr_attention.argtypes = [C.POINTER(AttnDesc), i, vp]
         l.lwdetr_gemm_tuning.argtypes = [i]
         l.lwdetr_gemm_tuning.restype = None
+        l.lwdetr_gemm_pt_tuning.argtypes = [i]
+        l.lwdetr_gemm_pt_tuning.restype = None
+        l.lwdetr_gemm_pt_count.argtypes = []
+        l.lwdetr_gemm_pt_count.restype = C.c_long
         l.lwdetr_attention_tuning.argtypes = [i]
         l.lwdetr_attention_tuning.restype = None
         l.lwdetr_attention_tuning_cfg.argtypes = [i]

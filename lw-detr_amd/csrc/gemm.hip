@@ -19,6 +19,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+// gemm_pt.hip: launches the persistent large-tile kernel if the shape is one of its own (taken = true), otherwise leaves the launch to this file
+int lwdetr_gemm_pt_try(const lwdetr_gemm_desc& d, int dtype, hipStream_t st, bool& taken);
+
 namespace {
 
 constexpr int BK = 32;
@@ -1709,6 +1712,11 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     if constexpr (AMODE == LWDETR_A_CONV3x3) {
         bool taken = false;
         const int rc = try_launch_conv_patch<T>(d, st, taken);
+        if (taken) return rc;
+    }
+    if constexpr (AMODE == LWDETR_A_PLAIN && sizeof(T) == 2) {       // round 6: the persistent form of the large-tile kernel (gemm_pt.hip) where it applies
+        bool taken = false;
+        const int rc = lwdetr_gemm_pt_try(d, std::is_same<T, f16>::value ? DT_F16 : DT_BF16, st, taken);
         if (taken) return rc;
     }
     {

@@ -395,6 +395,112 @@ def test_gemm_large_tile_kernel(dtype, mnk, depth):
     assert _relerr(plain, base.float()) < TOL[dtype]
 
 
+@pytest.fixture
+def pt_gemm():
+    """Route every legal GEMM through the persistent large-tile kernel (gemm_pt.hip; by default only >= 16384-row shapes take it)."""
+    from lwdetr_amd import _native
+    _native.lib().lwdetr_gemm_pt_tuning(2)
+    yield
+    _native.lib().lwdetr_gemm_pt_tuning(-1)
+
+
+def _pt_vs_big(run):
+    """run() once through the persistent kernel (asserting that it served the launch) and once through gemm_big_kernel; returns both result lists."""
+    from lwdetr_amd import _native
+    lib = _native.lib()
+    lib.lwdetr_gemm_tuning(2)
+    try:
+        lib.lwdetr_gemm_pt_tuning(2)
+        n0 = lib.lwdetr_gemm_pt_count()
+        a = run()
+        torch.cuda.synchronize()
+        assert lib.lwdetr_gemm_pt_count() > n0, "the persistent kernel refused a shape this test is meant to run on it"
+        lib.lwdetr_gemm_pt_tuning(0)
+        n1 = lib.lwdetr_gemm_pt_count()
+        b = run()
+        torch.cuda.synchronize()
+        assert lib.lwdetr_gemm_pt_count() == n1
+    finally:
+        lib.lwdetr_gemm_pt_tuning(-1)
+        lib.lwdetr_gemm_tuning(-1)
+    return a, b
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mnk", [(4096, 768, 768),        # 48 tiles: one per workgroup, most workgroups idle
+                                 (1000, 2304, 768),       # ragged last row tile (1000 = 3 x 256 + 232), 36 tiles
+                                 (8192, 3072, 768),       # 384 tiles: one or two per workgroup
+                                 (14592, 2304, 768),      # 513 tiles: two or three per workgroup (a quarter of xlarge's QKV)
+                                 (20000, 768, 192),       # nk = 3: the ring parity flips from tile to tile; ragged tail
+                                 (16392, 512, 128),       # nk = 2, the shortest contraction the kernel takes; 130 tiles, ragged by 8 rows
+                                 (6144, 768, 3072)])      # fc2 of the C = 768 model: 48 steps per tile
+def test_gemm_persistent_tile_kernel(dtype, mnk):
+    """gemm_pt_kernel (round 6: persistent workgroups, DMA ring running across tile boundaries, register-direct epilogue) vs torch and
+    vs gemm_big_kernel: bias + GELU + LayerScale + residual, plain bias, residual updated IN PLACE + tap copy (the ViT's fc2)."""
+    from lwdetr_amd import kernels as K
+    m, n, k = mnk
+    x = _rand(m, k, dtype=dtype, seed=1)
+    w = _rand(n, k, dtype=dtype, scale=k ** -0.5, seed=2)
+    bias = _rand(n, dtype=torch.float32, seed=3)
+    gamma = _rand(n, dtype=torch.float32, seed=4)
+    res = _rand(m, n, dtype=dtype, seed=5)
+
+    def run():
+        out = K.linear(x, w, bias, act=K.ACT_GELU, res=res, gamma=gamma)
+        plain = K.linear(x, w, bias)
+        silu = K.linear(x, w, bias, act=K.ACT_SILU)
+        inplace = res.clone()
+        taps = torch.full((m, n + 64), 7.0, dtype=dtype, device=_dev())
+        K.GemmOp(x, w, m, n, k, [K.seg(inplace, 0, n, ldo=n, bias=bias, gamma=gamma, res=inplace, ldres=n, out2=taps[:, 32:], ld2=n + 64)])()
+        return [out, plain, silu, inplace, taps]
+
+    pt, big = _pt_vs_big(run)
+    y = x.float() @ w.float().t() + bias
+    assert _relerr(pt[0], res.float() + gamma * F.gelu(y)) < TOL[dtype]
+    assert _relerr(pt[1], y) < TOL[dtype]
+    assert _relerr(pt[2], F.silu(y)) < TOL[dtype]
+    assert _relerr(pt[3], res.float() + gamma * y) < TOL[dtype]
+    assert torch.equal(pt[4][:, 32:32 + n], pt[3]) and bool((pt[4][:, :32] == 7.0).all()) and bool((pt[4][:, 32 + n:] == 7.0).all())
+    # against gemm_big_kernel: the same products summed from the bias instead of from zero, one scale multiplication instead of two -
+    # equal up to an f32 rounding or two in front of the 16-bit rounding (a few outputs land on the neighbouring 16-bit value)
+    for a, b, what in zip(pt, big, ("gelu + layerscale + residual", "bias", "silu", "in place", "taps")):
+        assert _relerr(a, b) < TOL[dtype] / 2, (what, _relerr(a, b))
+        assert (a != b).float().mean().item() < 0.02, (what, (a != b).float().mean().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("b,tp", [(4, 1600), (3, 1000), (2, 3648)])
+def test_gemm_persistent_tile_kernel_head_layouts(dtype, b, tp):
+    """QKV of the C = 768 model through the persistent kernel: HEADS (q with bias and scale, k) and HEADS_T (V^T: swapped MFMA operands, 8 consecutive
+    tokens per lane); tiles that straddle an image boundary at a non-aligned row (tp = 1000) and a ragged last tile; also against gemm_big_kernel."""
+    from lwdetr_amd import kernels as K
+    heads, hd = 12, 64
+    c = heads * hd
+    x = _rand(b * tp, c, dtype=dtype, seed=1)
+    w = _rand(3 * c, c, dtype=dtype, scale=c ** -0.5, seed=2)
+    qb, vb = _rand(c, seed=3), _rand(c, seed=4)
+
+    def run():
+        q = torch.zeros(b, heads, tp, hd, dtype=dtype, device=_dev())
+        k = torch.zeros_like(q)
+        vt = torch.zeros(b, heads, hd, tp, dtype=dtype, device=_dev())
+        K.GemmOp(x, w, b * tp, 3 * c, c, [
+            K.seg(q, 0, c, mode=K.OUT_HEADS, bias=qb, scale=0.37, p0=tp, p1=hd, p2=heads),
+            K.seg(k, c, 2 * c, mode=K.OUT_HEADS, p0=tp, p1=hd, p2=heads),
+            K.seg(vt, 2 * c, 3 * c, mode=K.OUT_HEADS_T, bias=vb, p0=tp, p1=hd, p2=heads)])()
+        return [q, k, vt]
+
+    pt, big = _pt_vs_big(run)
+    y = x.float() @ w.float().t()
+    sp = lambda t: t.reshape(b, tp, heads, hd).permute(0, 2, 1, 3)
+    assert _relerr(pt[0], sp((y[:, :c] + qb) * 0.37)) < TOL[dtype]
+    assert _relerr(pt[1], sp(y[:, c:2 * c])) < TOL[dtype]
+    assert _relerr(pt[2], sp(y[:, 2 * c:] + vb).transpose(2, 3)) < TOL[dtype]
+    for a, b_, what in zip(pt, big, "q k vt".split()):
+        assert _relerr(a, b_) < TOL[dtype] / 2, (what, _relerr(a, b_))
+        assert (a != b_).float().mean().item() < 0.02, (what, (a != b_).float().mean().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("hd", [64, 32, 16])
 @pytest.mark.parametrize("wg2", ["0", "2"])
