@@ -218,6 +218,17 @@ int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const float* b1_f
                      const float* gamma1, const void* wqkv_next, const float* bqkv_next, void* q_out, void* k_out,
                      void* vt_out, float qscale, int heads, int hd, int Tp, int dtype, void* hip_stream);
 
+/* The few-token form of lwdetr_mlp_fused with the attention projection (round 6; 16-bit, C = 192, M < 12800: the single-image latency path) on
+ * FRAGMENT-MAJOR weights: w1_frag, wp_frag, wqkv_frag_next = the w1_folded / wp / wqkv_next of lwdetr_mlp_fused re-laid out as
+ * [R / 16][C / 32][16][32] (lwdetr_amd.kernels.pack_frag16), so that each 16 x 32 MFMA fragment the kernel loads straight from L2 is one
+ * contiguous KB instead of 16 half lines. Everything else as lwdetr_mlp_fused (att required); results are bit-identical to it.
+ * LWDETR_ERR_UNSUPPORTED outside (C, dtype, M) above. */
+int lwdetr_vit_block_few(void* x, long ldx, const void* w1_frag, const float* b1_folded, const void* w2_chunked, const float* b2,
+                         const float* gamma2, void* out2, long ld2, float* stats_out, long M, int C, float eps, float eps_next,
+                         const void* att, long ldatt, const void* wp_frag, const float* bp, const float* gamma1,
+                         const void* wqkv_frag_next, const float* bqkv_next, void* q_out, void* k_out, void* vt_out, float qscale,
+                         int heads, int hd, int Tp, int dtype, void* hip_stream);
+
 /* ---- fused ViT block tail (round 3; 16-bit dtypes, C in {192, 384}, M % 4 == 0) --------------------------------------
  * Replaces, per ViT block, models/backbone/vit.py:138 + :206-216 (attention output projection, gamma_1, residual),
  * :217-218 (norm2 -> timm Mlp -> gamma_2 -> residual) and, with has_qkv, :199 + :123-130 of the NEXT block (norm1, QKV with

@@ -104,6 +104,8 @@ def lib():
         l.lwdetr_ffn_finish.argtypes = [vp, lg, vp, i, vp, vp, vp, f, vp, lg, vp, vp, f, vp, lg, lg, i, i, vp]
         l.lwdetr_mlp_fused.argtypes = [vp, lg, vp, vp, vp, vp, vp, vp, lg, vp, lg, i, f, f, vp, lg, vp, vp, vp,
                                        vp, vp, vp, vp, vp, f, i, i, i, i, vp]
+        l.lwdetr_vit_block_few.argtypes = [vp, lg, vp, vp, vp, vp, vp, vp, lg, vp, lg, i, f, f, vp, lg, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, f, i, i, i, i, vp]
         l.lwdetr_vit_block.argtypes = [vp, lg, vp, lg, vp, vp, vp, lg, vp, lg, i, f, f, i, vp, vp, vp, f, i, i, i, i, vp]
         l.lwdetr_vit_block_stream_bytes.argtypes = [i, i]
         l.lwdetr_vit_block_stream_bytes.restype = C.c_long
@@ -144,7 +146,7 @@ def lib():
         l.lwdetr_prof_kernel_name.restype = C.c_char_p
         l.lwdetr_prof_collect.argtypes = [vp, vp, vp, vp, i]
         for fn in ("lwdetr_msda_forward", "lwdetr_msda_backward", "lwdetr_msda_fused_forward", "lwdetr_gemm", "lwdetr_attention",
-                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_row_stats", "lwdetr_enc_chain", "lwdetr_row_chain", "lwdetr_mlp_fused", "lwdetr_vit_block", "lwdetr_vit_qkv", "lwdetr_vit_stem", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
+                   "lwdetr_layernorm", "lwdetr_layernorm_chain", "lwdetr_row_stats", "lwdetr_enc_chain", "lwdetr_row_chain", "lwdetr_mlp_fused", "lwdetr_vit_block_few", "lwdetr_vit_block", "lwdetr_vit_qkv", "lwdetr_vit_stem", "lwdetr_ffn_splits", "lwdetr_ffn_partial", "lwdetr_ffn_finish", "lwdetr_select_gather", "lwdetr_decoder_inputs",
                    "lwdetr_box_reparam", "lwdetr_rowmax", "lwdetr_topk", "lwdetr_postprocess", "lwdetr_postprocess_packed", "lwdetr_finalize_outputs", "lwdetr_resize_normalize", "lwdetr_prof_enable", "lwdetr_prof_num_kernels", "lwdetr_prof_collect"):
             getattr(l, fn).restype = C.c_int
         _lib = l

@@ -77,6 +77,7 @@ struct MlpParams {
     // [y * chunks_per_split, (y + 1) * chunks_per_split) of its tiles and writes the f32 partial products of linear2 to
     // partial[y][m][C]; no LayerNorm, no residual (lwdetr_ffn_finish sums the slabs)
     float* partial; int chunks_per_split;
+    int wfrag;                         // few-token kernel: Wp / W1 / Wqkv are fragment-major (lwdetr_vit_block_few)
 };
 
 template <typename T, int C, int TT, bool PROJ, bool QKV, bool FFN = false>
@@ -525,9 +526,12 @@ __global__ __launch_bounds__(NTHR, MLP_WAVES_PER_SIMD) void mlp_kernel(const Mlp
 // for one 640 x 640 image on 256 CUs) and, with half the accumulators, room to keep the fc2 fragments of a chunk and the
 // fc1 fragments of the wave's NEXT chunk in flight while the current one multiplies - the kernel is a chain of L2 round
 // trips for weights (two per hidden chunk, one per QKV feature tile), and at this size nothing else matters.
-template <typename T, bool QKV, int TT>
+template <typename T, bool QKV, int TT, bool FRAG = false>
 __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
     constexpr int C = 192, KC = C / 32, NT = C / 16, HID = 4 * C, X1_LD = C + 8;
+    // FRAG: Wp, W1 and Wqkv arrive fragment-major - [row tile of 16][k-chunk of 32][16][32], every 16 x 32 MFMA A fragment one contiguous KB
+    // (lwdetr_amd.kernels.pack_frag16) - instead of row-major: a fragment load is then 8 whole 128-byte lines instead of 16 half lines 384 bytes apart
+    auto frag = [&](const T* w, int rt, int kc, int l15_, int g_) { return FRAG ? w + ((long)(rt * KC + kc) * 16 + l15_) * 32 + g_ * 8 : w + (long)(rt * 16 + l15_) * C + kc * 32 + g_ * 8; };
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     static_assert(sizeof(T) == 2, "");
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) wa[h][kc] = *(const V8*)(WP + (long)(pc * 32 + h * 16 + l15) * C + kc * 32 + g * 8);
+            for (int kc = 0; kc < KC; ++kc) wa[h][kc] = *(const V8*)frag(WP, pc * 2 + h, kc, l15, g);
 #pragma unroll
             for (int t = 0; t < TT; ++t) xr[h][t] = *(const V4*)(X + mrow[t] * p.ldx + pc * 32 + h * 16 + g * 4);
         }
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
         // fragments of a chunk before its fc1 MFMAs: one L2 round trip per chunk is exposed instead of two
         V8 f1[2 * KC];
 #pragma unroll
-        for (int i = 0; i < 2 * KC; ++i) f1[i] = *(const V8*)(W1 + (long)(wave * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
+        for (int i = 0; i < 2 * KC; ++i) f1[i] = *(const V8*)frag(W1, wave * 2 + (i & 1), i >> 1, l15, g);
 #pragma unroll 1
         for (int hc = wave; hc < HID / 32; hc += NW) {
             V8 f2[NT];
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
             for (int i = 0; i < 2 * KC; ++i) acc1[i & 1] = Mma<T>::k32(f1[i], xf[0][i >> 1], acc1[i & 1]);
             const int hn = hc + NW < HID / 32 ? hc + NW : hc;            // last chunk: a harmless reload
 #pragma unroll
-            for (int i = 0; i < 2 * KC; ++i) f1[i] = *(const V8*)(W1 + (long)(hn * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
+            for (int i = 0; i < 2 * KC; ++i) f1[i] = *(const V8*)frag(W1, hn * 2 + (i & 1), i >> 1, l15, g);
             V8 hf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
             V8 fr[2 * KC];
     #pragma unroll
             for (int i = 0; i < 2 * KC; ++i)        // fc1 fragment i = (kc = i / 2, h = i % 2)
-                fr[i] = *(const V8*)(W1 + (long)(hc * 32 + (i & 1) * 16 + l15) * C + (i >> 1) * 32 + g * 8);
+                fr[i] = *(const V8*)frag(W1, hc * 2 + (i & 1), i >> 1, l15, g);
             const f32x4 bia0 = *(const f32x4*)(b1s + hc * 32 + g * 4), bia1 = *(const f32x4*)(b1s + hc * 32 + 16 + g * 4);
             f32x4 acc1[2][TT];
     #pragma unroll
@@ -752,14 +756,14 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
     constexpr int NIT = (NTQ + NW - 1) / NW;
     V8 wq[2][KC];
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) wq[0][kc] = *(const V8*)(WQ + (long)(wave * 16 + l15) * C + kc * 32 + g * 8);
+    for (int kc = 0; kc < KC; ++kc) wq[0][kc] = *(const V8*)frag(WQ, wave, kc, l15, g);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int nt = wave + it * NW;
         if (it + 1 < NIT) {
             const int ntn = nt + NW < NTQ ? nt + NW : NTQ - 1;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) wq[(it + 1) & 1][kc] = *(const V8*)(WQ + (long)(ntn * 16 + l15) * C + kc * 32 + g * 8);
+            for (int kc = 0; kc < KC; ++kc) wq[(it + 1) & 1][kc] = *(const V8*)frag(WQ, ntn, kc, l15, g);
         }
         if (nt >= NTQ) break;                                          // wave-uniform
         const int sg = nt / (C / 16), nl0 = (nt - sg * (C / 16)) * 16;
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(NTHR, 1) void mlp_small_kernel(const MlpParams p) {
     }
 }
 constexpr long MLP_SMALL_TT1_MAX_ROWS = 3200;      // one or two 640 x 640 images: 16-token workgroups (see mlp_small_kernel)
-template <typename T, bool QKV, int TT>
+template <typename T, bool QKV, int TT, bool FRAG = false>
 int launch_mlp_small_tt(const MlpParams& p, hipStream_t st) {
     constexpr int C = 192;
     constexpr size_t lds = 16 * TT * (C + 8) * sizeof(T) + (size_t)NW * 6 * TT * 256 * sizeof(float) + 11 * C * sizeof(float);
@@ -797,19 +801,20 @@ int launch_mlp_small_tt(const MlpParams& p, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return LWDETR_ERR_LAUNCH;
     if (!attr_done[dev]) {
-        if (hipFuncSetAttribute((const void*)mlp_small_kernel<T, QKV, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)mlp_small_kernel<T, QKV, TT, FRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return LWDETR_ERR_LAUNCH;
         attr_done[dev] = true;
     }
     const long blocks = (p.M + 16 * TT - 1) / (16 * TT);
     ProfScope ps(KID_MLP, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C, (double)p.M * C * sizeof(T) * 3 + (QKV ? 3.0 : 0.0) * p.M * C * sizeof(T), st);
-    hipLaunchKernelGGL((mlp_small_kernel<T, QKV, TT>), dim3((unsigned)blocks), dim3(NTHR), lds, st, p);
+    hipLaunchKernelGGL((mlp_small_kernel<T, QKV, TT, FRAG>), dim3((unsigned)blocks), dim3(NTHR), lds, st, p);
     return lwdetr_check_launch();
 }
 template <typename T, bool QKV>
 int launch_mlp_small(const MlpParams& p, hipStream_t st) {
     static const char* env = getenv("LWDETR_MLP_SMALL_TT");          // tuning: 1 / 2 = tokens tiles per workgroup
     const int tt = env ? atoi(env) : (p.M <= MLP_SMALL_TT1_MAX_ROWS ? 1 : 2);
+    if (p.wfrag) return tt == 1 ? launch_mlp_small_tt<T, QKV, 1, true>(p, st) : launch_mlp_small_tt<T, QKV, 2, true>(p, st);
     return tt == 1 ? launch_mlp_small_tt<T, QKV, 1>(p, st) : launch_mlp_small_tt<T, QKV, 2>(p, st);
 }
 
@@ -920,6 +925,7 @@ extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const 
     if (ldx % 8 != 0 || (out2 && ld2 % 8 != 0)) return LWDETR_ERR_BAD_ARG;
     if (att && (!wp || !bp || !gamma1 || ldatt % 8 != 0)) return LWDETR_ERR_BAD_ARG;
     MlpParams p;
+    p.wfrag = 0;
     p.att = att; p.ldatt = ldatt; p.wp = wp; p.bp = bp; p.gamma1 = gamma1;
     p.wqkv = wqkv_next; p.bqkv = bqkv_next; p.q = q_out; p.k = k_out; p.vt = vt_out; p.qscale = qscale;
     p.heads = heads; p.hd = hd; p.Tp = Tp;
@@ -935,6 +941,35 @@ extern "C" int lwdetr_mlp_fused(void* x, long ldx, const void* w1_folded, const 
         case DT_F32: return dispatch_c<float, 1, 1>(p, C, st);
         default: return LWDETR_ERR_UNSUPPORTED;
     }
+}
+
+// The few-token form on its own entry point, with FRAGMENT-MAJOR weights (round 6). mlp_small_kernel streams every weight straight from L2 into
+// MFMA A fragments (16 rows x 32 k per wave-load); out of a row-major (R, 192) matrix such a load is 16 segments of 64 bytes, 384 bytes apart -
+// half lines - and the kernel's time WAS that load path: with Wp / W1 / Wqkv re-laid out so that every fragment is one contiguous KB
+// (lwdetr_amd.kernels.pack_frag16: [R / 16][K / 32][16][32]; W2 is chunk-major already) a block launch at one 640 x 640 image goes 30 -> 22 us,
+// the single-image forward 0.857 -> 0.786 ms (profiles/r6b_*). Same arithmetic, bit-identical results.
+extern "C" int lwdetr_vit_block_few(void* x, long ldx, const void* w1_frag, const float* b1_folded, const void* w2_chunked, const float* b2,
+                                    const float* gamma2, void* out2, long ld2, float* stats_out, long M, int C, float eps, float eps_next,
+                                    const void* att, long ldatt, const void* wp_frag, const float* bp, const float* gamma1,
+                                    const void* wqkv_frag_next, const float* bqkv_next, void* q_out, void* k_out, void* vt_out, float qscale,
+                                    int heads, int hd, int Tp, int dtype, void* hip_stream) {
+    if (!x || !w1_frag || !b1_folded || !w2_chunked || !b2 || !gamma2 || !att || !wp_frag || !bp || !gamma1 || M < 0) return LWDETR_ERR_BAD_ARG;
+    if (M == 0) return LWDETR_OK;
+    if (C != 192 || (dtype != DT_F16 && dtype != DT_BF16) || M >= MLP_SMALL_MAX_ROWS) return LWDETR_ERR_UNSUPPORTED;
+    if (ldx % 8 != 0 || (out2 && ld2 % 8 != 0) || ldatt % 8 != 0) return LWDETR_ERR_BAD_ARG;
+    if (wqkv_frag_next && (!bqkv_next || !q_out || !k_out || !vt_out || heads <= 0 || hd % 4 != 0 || heads * hd != C || Tp % 4 != 0 || M % 4 != 0))
+        return LWDETR_ERR_BAD_ARG;
+    MlpParams p;
+    p.wfrag = 1;
+    p.att = att; p.ldatt = ldatt; p.wp = wp_frag; p.bp = bp; p.gamma1 = gamma1;
+    p.wqkv = wqkv_frag_next; p.bqkv = bqkv_next; p.q = q_out; p.k = k_out; p.vt = vt_out; p.qscale = qscale;
+    p.heads = heads; p.hd = hd; p.Tp = Tp;
+    p.x = x; p.ldx = ldx; p.w1 = w1_frag; p.b1 = b1_folded; p.w2p = w2_chunked; p.b2 = b2; p.gamma2 = gamma2;
+    p.out2 = out2; p.ld2 = ld2; p.stats_out = stats_out; p.M = M; p.eps = eps; p.eps_next = eps_next;
+    p.partial = nullptr; p.chunks_per_split = 0; p.ntiles = 0;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (dtype == DT_F16) return p.wqkv ? launch_mlp_small<f16, true>(p, st) : launch_mlp_small<f16, false>(p, st);
+    return p.wqkv ? launch_mlp_small<bf16, true>(p, st) : launch_mlp_small<bf16, false>(p, st);
 }
 
 // ---- decoder FFN, first half: partial[s] (M, C) f32 = ReLU(x W1[hs]^T + b1[hs]) W2[:, hs]^T over the hidden slice hs of split s.

@@ -302,6 +302,12 @@ def pack_qkv_weights(wqkv, q_bias, v_bias, ln_w, ln_b, dtype):
     return w.to(dtype).contiguous(), bias.contiguous()
 
 
+def pack_frag16(w):
+    """(R, K) row-major -> fragment-major [R / 16][K / 32][16][32]: every 16 x 32 MFMA A fragment one contiguous KB (few-token block kernel)."""
+    r, k = w.shape
+    return w.view(r // 16, 16, k // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
 class MlpFusedOp:
     """x <- x + gamma2 * fc2(GELU(fc1(LN(x)))) in one launch (weights packed by ``pack_mlp_weights``)."""
 
@@ -323,6 +329,25 @@ class MlpFusedOp:
         rc = self._fn(*self.args, stream if stream is not None else _nat.stream_ptr())
         if rc:
             _nat.check(rc, "mlp_fused")
+
+
+VIT_BLOCK_FEW_MAX_ROWS = 12800      # = MLP_SMALL_MAX_ROWS of csrc/mlp.hip
+
+
+def vit_block_few_supported(C_, dtype, rows) -> bool:
+    """The launch-plan choice for lwdetr_vit_block_few (the few-token block kernel on fragment-major weights): 16-bit C = 192 below
+    ~8 images of 640 x 640. LWDETR_VIT_BLOCK_FEW=0 keeps the row-major form (lwdetr_mlp_fused; A/B runs)."""
+    return (C_ == 192 and dtype in (torch.float16, torch.bfloat16) and rows is not None and rows < VIT_BLOCK_FEW_MAX_ROWS
+            and os.environ.get("LWDETR_VIT_BLOCK_FEW", "1") != "0")
+
+
+class VitBlockFewOp(MlpFusedOp):
+    """MlpFusedOp with the attention projection on fragment-major Wp / W1 / Wqkv (``pack_frag16`` of what MlpFusedOp takes): lwdetr_vit_block_few."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        assert k.get("att") is not None
+        self._fn = _nat.lib().lwdetr_vit_block_few
 
 
 # ---------------------------------------------------------------------------------------- fused ViT block (round 3)

@@ -752,6 +752,51 @@ def test_mlp_fused(dtype, c, m):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,tp", [(1600, 1600), (3200, 1600), (6400, 1600), (1000, 100), (2496, 624), (12000, 400)])
+def test_vit_block_few_fragment_major_weights(dtype, m, tp):
+    """lwdetr_vit_block_few (round 6: the few-token ViT block kernel on fragment-major Wp / W1 / Wqkv - pack_frag16) is the arithmetic of
+    lwdetr_mlp_fused bit for bit: residual stream, tap copy, row statistics, chained q / k / v^T; also against the torch fp32 formulation.
+    1600 / 3200 rows = one / two 640 x 640 images (16-token workgroups), the rest 32-token workgroups incl. ragged tile counts."""
+    from lwdetr_amd import kernels as K
+    c, heads = 192, 12
+    hd = c // heads
+    assert K.vit_block_few_supported(c, dtype, m)
+    x = _rand(m, c, dtype=dtype, seed=1) * 2 + 0.3
+    att = _rand(m, c, dtype=dtype, seed=9)
+    w1, b1 = _rand(4 * c, c, scale=c ** -0.5, seed=2), _rand(4 * c, seed=3) * 0.1
+    w2, b2 = _rand(c, 4 * c, scale=(4 * c) ** -0.5, seed=4), _rand(c, seed=5) * 0.1
+    lw, lb = _rand(c, seed=6) * 0.2 + 1, _rand(c, seed=7) * 0.1
+    g2, g1 = _rand(c, seed=8) * 0.3, _rand(c, seed=12) * 0.3
+    wp, bp = _rand(c, c, scale=c ** -0.5, seed=10), _rand(c, seed=11) * 0.1
+    wqkv = _rand(3 * c, c, scale=c ** -0.5, seed=13)
+    qb, vb = _rand(c, seed=14) * 0.1, _rand(c, seed=15) * 0.1
+    lw1, lb1 = _rand(c, seed=16) * 0.2 + 1, _rand(c, seed=17) * 0.1
+    w1p, b1p, w2p = K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype, proj=True)
+    wq, bq = K.pack_qkv_weights(wqkv, qb, vb, lw1, lb1, dtype)
+    wpd = wp.to(dtype).contiguous()
+    nb = m // tp
+    res = []
+    for few in (False, True):
+        xx = x.clone()
+        taps = torch.full((m, 2 * c), 7.0, dtype=dtype, device=_dev())
+        stats = torch.zeros(m, 2, device=_dev())
+        q = torch.zeros(nb, heads, tp, hd, dtype=dtype, device=_dev())
+        k = torch.zeros_like(q)
+        vt = torch.zeros(nb, heads, hd, tp, dtype=dtype, device=_dev())
+        cls = K.VitBlockFewOp if few else K.MlpFusedOp
+        f = K.pack_frag16 if few else (lambda t: t)
+        cls(xx, f(w1p), b1p, w2p, b2, g2, m, c, 1e-6, out2=taps[:, c:], ld2=2 * c, stats_out=stats, att=att, wp=f(wpd), bp=bp, gamma1=g1,
+            wqkv=f(wq), bqkv=bq, q=q, k=k, vt=vt, qscale=0.37, heads=heads, hd=hd, Tp=tp)()
+        res.append((xx, taps, stats, q, k, vt))
+    for a, b, what in zip(res[1], res[0], "x taps stats q k vt".split()):
+        assert torch.equal(a, b), (what, (a.float() - b.float()).abs().max().item())
+    x1 = (x.float() + g1 * (att.float() @ wp.t() + bp)).to(dtype).float()
+    ref = x1 + g2 * (F.gelu(F.layer_norm(x1, (c,), lw, lb, 1e-6) @ w1.t() + b1) @ w2.t() + b2)
+    assert _relerr(res[1][0], ref) < {torch.float16: 6e-3, torch.bfloat16: 5e-2}[dtype]
+    assert bool((res[1][1][:, :c] == 7.0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("c,heads,m,tp", [(192, 6, 51200, 1600), (192, 12, 12800, 400), (192, 3, 20000, 400), (192, 6, 64000, 1600),
                                           (384, 12, 25600, 1600), (384, 12, 12816, 4272), (192, 6, 13000, 1000)])
 @pytest.mark.parametrize("half", ["0", "1"])
