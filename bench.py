@@ -130,17 +130,22 @@ def cpu_baseline(size, res):
     processes; the sweep times 1 x all-cores, and N x 8 / N x 16 threads with every worker pinned to its own cores, and
     reports the best arrangement (all of them are listed in `sweep`)."""
     cores = len(os.sched_getaffinity(0))
-    plans = [(1, min(cores, 32))]
-    for t in (8, 16):
-        if cores // t >= 2:
-            plans.append((cores // t, t))
+    quota = _host_cpu_facts().get("cgroup_quota_cores")
+    # Round 6 (VERDICT r5 item 6c): arrangements that start more threads than twice the container's CPU quota only measure the throttle (the GPU
+    # box shows 256 logical CPUs with 16 CPUs' worth of time: 32 x 8 threads ran at load average 27 with 800 throttled periods) - the thread
+    # budget of the sweep is min(visible CPUs, 2 x quota); and the winner is run three times in all: `value` = the median, `spread` = min / max.
+    budget = cores if not quota else max(2, min(cores, int(round(2 * quota))))
+    plans = [(1, min(budget, 32))]
+    for t in (8, 16, 4):
+        if budget // t >= 2 and (budget // t, t) not in plans:
+            plans.append((budget // t, t))
     sweep, best, kind = [], None, "port"
     t_begin = time.time()
     for procs, threads in plans:
-        if time.time() - t_begin > 100:
+        if time.time() - t_begin > 70:
             break
         try:
-            ips, kind = _run_cpu_workers(size, res, procs, threads, cores, 6.0)
+            ips, kind = _run_cpu_workers(size, res, procs, threads, cores, 5.0)
         except Exception as e:      # noqa: BLE001 - the baseline is informational; never lose the GPU measurement
             sweep.append({"procs": procs, "threads": threads, "error": repr(e)[:120]})
             continue
@@ -149,6 +154,16 @@ def cpu_baseline(size, res):
             best = (ips, procs, threads)
     if best is None:
         return {"value": None, "unit": "images/sec", "cores": cores, "kind": kind, "sample": "failed", "sweep": sweep}
+    reruns = [best[0]]
+    for _ in range(2):
+        if time.time() - t_begin > 130:
+            break
+        try:
+            reruns.append(_run_cpu_workers(size, res, best[1], best[2], cores, 5.0)[0])
+        except Exception:       # noqa: BLE001
+            break
+    reruns.sort()
+    best = (reruns[len(reruns) // 2], best[1], best[2])
     what = ("the unmodified reference (oracle/ref_shims.py import shims)" if kind == "reference" else
             "oracle/lwdetr_torch.py (CPU restatement of the reference PyTorch path; /root/reference is absent on this box)")
     host = _host_cpu_facts()
@@ -158,9 +173,10 @@ def cpu_baseline(size, res):
     # container (the GPU box shows 256 logical CPUs with a quota of 16 CPUs' worth of time: threads beyond it are throttled)
     eff = used if not quota else min(used, max(1, int(round(quota))))
     return {"value": round(best[0], 2), "unit": "images/sec", "cores": eff, "threads_started": used, "kind": kind,
-            "cpu_model": _cpu_model_string(), "host_cores": cores, "host": host,
-            "sample": f"{best[1]} worker process(es) x {best[2]} threads, ~6 s of batch-2 forwards each at {res}x{res}, "
-                      f"fp32, {what}", "sweep": sweep}
+            "runs_of_the_winner": [round(v, 2) for v in reruns], "spread": [round(reruns[0], 2), round(reruns[-1], 2)],
+            "cpu_model": _cpu_model_string(), "host_cores": cores, "host": host, "thread_budget": budget,
+            "sample": f"{best[1]} worker process(es) x {best[2]} threads, ~5 s of batch-2 forwards each at {res}x{res}, "
+                      f"fp32, {what}; value = median of {len(reruns)} runs of this arrangement", "sweep": sweep}
 
 
 def _host_cpu_facts():
@@ -299,6 +315,98 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+# ---- GPU telemetry beside the timed region (round 6): the boxes of this pool differ by 12-15 % on the same tree and the record
+# carried no clock, power or temperature to tell a slow draw from a slow tree. Read from the card's sysfs hwmon files (microseconds per sample, no
+# subprocess, nothing on the GPU); `rocm-smi --json` once as the fallback. All failures are swallowed: telemetry never costs the line.
+def _hwmon_dir():
+    import glob
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        try:
+            if open(os.path.join(card, "vendor")).read().strip() != "0x1002":
+                continue
+        except OSError:
+            continue
+        hw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*")))
+        if hw:
+            return hw[0]
+    return None
+
+
+_HWMON = {"sclk_mhz": ("freq1_input", 1e-6), "mclk_mhz": ("freq2_input", 1e-6), "power_w": ("power1_average", 1e-6), "power_input_w": ("power1_input", 1e-6),
+          "temp_edge_c": ("temp1_input", 1e-3), "temp_junction_c": ("temp2_input", 1e-3), "temp_mem_c": ("temp3_input", 1e-3)}
+
+
+def gpu_telemetry(hw=None):
+    """{sclk_mhz, mclk_mhz, power_w, temp_*_c} right now, or {} (no readable source)."""
+    out = {}
+    hw = hw or _hwmon_dir()
+    if hw:
+        for k, (f, sc) in _HWMON.items():
+            try:
+                out[k] = round(int(open(os.path.join(hw, f)).read().strip()) * sc, 1)
+            except (OSError, ValueError):
+                pass
+    if out:
+        out["source"] = "sysfs hwmon"
+        return out
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=10)
+        card = next(iter(json.loads(r.stdout).values()))
+        for k, v in card.items():
+            kl = k.lower()
+            num = "".join(ch for ch in str(v) if ch.isdigit() or ch == ".")
+            if not num:
+                continue
+            if "sclk" in kl and "mhz" in str(v).lower() or kl.startswith("sclk clock speed"):
+                out["sclk_mhz"] = float(num)
+            elif "mclk" in kl:
+                out["mclk_mhz"] = float(num)
+            elif "power" in kl and "(w)" in kl:
+                out["power_w"] = float(num)
+            elif "temperature" in kl and "edge" in kl:
+                out["temp_edge_c"] = float(num)
+            elif "temperature" in kl and "junction" in kl:
+                out["temp_junction_c"] = float(num)
+        if out:
+            out["source"] = "rocm-smi --json"
+    except Exception:      # noqa: BLE001
+        pass
+    return out
+
+
+class TelemetrySampler:
+    """Samples gpu_telemetry() every few ms on a thread while a NON-reported pass runs (never during the timed region: a Python thread beside the
+    launching one is not free); .stop() -> {key: [min, mean, max]} of what the card did under this workload's load."""
+
+    def __init__(self, period=0.004):
+        import threading
+        self.hw, self.period, self.rows, self._stop = _hwmon_dir(), period, [], threading.Event()
+        self.th = threading.Thread(target=self._run, daemon=True) if self.hw else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.rows.append(gpu_telemetry(self.hw))
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.th:
+            self.th.start()
+        return self
+
+    def stop(self):
+        if not self.th:
+            return {}
+        self._stop.set()
+        self.th.join(timeout=1.0)
+        out = {"samples": len(self.rows)}
+        for k in ("sclk_mhz", "mclk_mhz", "power_w", "power_input_w", "temp_junction_c"):
+            v = [r[k] for r in self.rows if k in r]
+            if v:
+                out[k] = [min(v), round(sum(v) / len(v), 1), max(v)]
+        return out
+
+
 def main():
     a = parse()
     if a.cpu_baseline_worker:
@@ -344,12 +452,14 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
+    tele_before = gpu_telemetry() if rank == 0 else {}
     log("timing")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         det = step()
     barrier()
     dt = time.perf_counter() - t0
+    tele_after = gpu_telemetry() if rank == 0 else {}
     dt_nog = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -371,13 +481,17 @@ def main():
     # three more passes of the same K steps AFTER the reported region (never part of `value`): a slow draw of the box or of the one
     # timed region shows in the record
     extra_passes = []
-    for _ in range(3):
+    tele_load = {}
+    for ip in range(3):
         barrier()
+        sampler = TelemetrySampler().start() if (rank == 0 and ip == 2) else None       # the LAST of them carries the sampling thread (clocks / power under load)
         t1 = time.perf_counter()
         for _ in range(a.steps):
             step()
         barrier()
         tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if sampler:
+            tele_load = sampler.stop()
         if world > 1:
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         extra_passes.append(tt.item())
@@ -392,14 +506,18 @@ def main():
                    "collective": "all_gather_into_tensor of (B,K,6) f32 detections" if grouped else "none", "backend": backend,
                    "launch_chains": type(model)._chains_for(a.batch, a.res, a.res)},
     }
+    all_ms = sorted([ms_step] + [t / a.steps * 1e3 for t in extra_passes])
     result["ms_per_step_passes"] = {"timed": round(ms_step, 3), "after": [round(t / a.steps * 1e3, 3) for t in extra_passes],
-                                    "note": "value / ms_per_step come from `timed` alone; `after` = three more passes of the same K steps outside the timed region"}
+                                    "median_of_all": round((all_ms[1] + all_ms[2]) / 2, 3), "median_images_per_sec": round(world * a.batch / ((all_ms[1] + all_ms[2]) / 2) * 1e3, 1),
+                                    "note": "value / ms_per_step come from `timed` alone; `after` = three more passes of the same K steps outside the timed region "
+                                            "(the third with a telemetry sampling thread beside it); median_* = over the four"}
     try:
         pr = torch.cuda.get_device_properties(dev)
         import hashlib, socket
         result["config"]["box"] = {"device": pr.name, "cus": pr.multi_processor_count, "mem_gb": round(pr.total_memory / 2 ** 30),
                                    "clock_mhz": getattr(pr, "clock_rate", 0) // 1000, "gcn_arch": getattr(pr, "gcnArchName", ""),
-                                   "host": hashlib.sha1(socket.gethostname().encode()).hexdigest()[:8]}
+                                   "host": hashlib.sha1(socket.gethostname().encode()).hexdigest()[:8],
+                                   "telemetry": {"before_timed_region": tele_before, "after_timed_region": tele_after, "under_load_last_pass": tele_load}}
     except Exception as e:                      # never fail the line over a label
         result["config"]["box"] = {"error": str(e)[:80]}
     if rank == 0 and backend == "nccl":

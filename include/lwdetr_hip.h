@@ -133,6 +133,10 @@ int lwdetr_row_stats(const void* x, long ldx, long M, int C, float eps, float* s
  * shape thresholds), 0 = never use the 256-row large-tile kernel, 2 = use it whenever the shape is legal for it,
  * 32 / 64 = as 2 with that stage depth. Results do not depend on it beyond f32 summation order. */
 void lwdetr_gemm_tuning(int big_mode);
+/* 1 if the library was built with -DLWDETR_EXPERIMENTS: the kernel forms that were built, validated and measured SLOWER than what the launch plan
+ * uses (round 5: the 4-wave / 128-row large-tile GEMM, the LayerNorm-folded GEMM epilogue behind ln_stats, split-K behind splitk, the LDS window-tile
+ * attention kernel) are only compiled then. The default library (0) answers such requests with LWDETR_ERR_UNSUPPORTED or takes the ordinary kernel. */
+int lwdetr_has_experiments(void);
 /* The persistent large-tile kernel (round 6, csrc/gemm_pt.hip: a workgroup walks its 256 x 256 tiles, the DMA ring runs on across tile boundaries,
  * the epilogue goes straight from the accumulators to memory) serves the 16-bit plain-A launches whose segments are whole 256-column tiles of
  * LINEAR / HEADS / HEADS_T outputs - the four Linear layers of a C = 768 ViT block (models/backbone/vit.py:123-138, :217-218). Process-wide
@@ -365,6 +369,15 @@ typedef struct {
 } lwdetr_resize_image;
 int lwdetr_resize_normalize(const lwdetr_resize_image* images, int B, int max_height, const int32_t* tables, uint8_t* tmp,
                             const float* lut, void* out, int S, int dtype, void* hip_stream);
+
+/* ---- run-time switches (tuning, A/B runs, tests). Every environment variable LWDETR_<NAME> that a launch path of this library looks at
+ * (kernel choices and shapes: ATTN_LDS, ATTN_LDS_CFG, ATTN_SHORT, ATTN_WTILE, ATTN_WIN, ATTN_QT, CHAIN_SPLIT_ROWS, GEMM_BIG, GEMM_BIG_BN, GEMM_BIG_2WG,
+ * CONV_PATCH, GEMM_TILE, GEMM_DMA, GEMM_KB, GEMM_NST, GEMM_PT, GEMM_PT_SKEW, MLP_SMALL_TT, FFN_SPLITS, MLP_SMALL, VB_GRID, VB_GELU16, VB_HALF) is read
+ * ONCE per process into a table; no launch calls getenv. lwdetr_tuning_set overrides (is_set != 0) or clears (is_set == 0: back to the built-in
+ * default, not to the environment) one entry by name, with or without the LWDETR_ prefix; LWDETR_ERR_BAD_ARG for an unknown name. Process-wide,
+ * not synchronised with launches in flight on other threads. Results never depend on a switch beyond f32 summation order, except VB_GELU16
+ * (DESIGN.md section 2). */
+int lwdetr_tuning_set(const char* name, long value, int is_set);
 
 /* ---- profiling: per-kernel HIP-event timing on the launch stream (off by default) ------------------------------ */
 int lwdetr_prof_enable(int on);

@@ -88,6 +88,7 @@ def lib():
         l.lwdetr_attention.argtypes = [C.POINTER(AttnDesc), i, vp]
         l.lwdetr_gemm_tuning.argtypes = [i]
         l.lwdetr_gemm_tuning.restype = None
+        l.lwdetr_has_experiments.argtypes = []
         l.lwdetr_gemm_pt_tuning.argtypes = [i]
         l.lwdetr_gemm_pt_tuning.restype = None
         l.lwdetr_gemm_pt_count.argtypes = []
@@ -140,6 +141,7 @@ def lib():
         l.lwdetr_postprocess_packed.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp]
         l.lwdetr_finalize_outputs.argtypes = [vp, vp, lg, vp, lg, vp, lg, i, vp, lg, i, vp]
         l.lwdetr_resize_normalize.argtypes = [vp, i, i, vp, vp, vp, vp, i, i, vp]
+        l.lwdetr_tuning_set.argtypes = [C.c_char_p, lg, i]
         l.lwdetr_prof_enable.argtypes = [i]
         l.lwdetr_prof_num_kernels.argtypes = []
         l.lwdetr_prof_kernel_name.argtypes = [i]
@@ -177,6 +179,12 @@ def require_cuda(*tensors):
 
 
 # ----------------------------------------------------------------------------------------------- profiling
+def tuning_set(name: str, value=None):
+    """Override (value: int) or clear (None) one launch-path switch of the library (lwdetr_tuning_set; the LWDETR_* environment is read once per
+    process, so tests and tools that switch inside a process go through here)."""
+    check(lib().lwdetr_tuning_set(name.encode(), 0 if value is None else int(value), 0 if value is None else 1), f"tuning_set({name})")
+
+
 def prof_enable(on: bool):
     check(lib().lwdetr_prof_enable(1 if on else 0), "prof_enable")
 

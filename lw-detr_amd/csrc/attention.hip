@@ -660,8 +660,7 @@ int launch_lds(const lwdetr_attn_desc& p, hipStream_t st) {
 int g_attn_lds_cfg = 0;         // lwdetr_attention_tuning_cfg(): overrides the environment / default (tests)
 template <typename T, int HD>
 int launch_lds_cfg(const lwdetr_attn_desc& p, hipStream_t st) {
-    static const char* cfg = getenv("LWDETR_ATTN_LDS_CFG");
-    int c = g_attn_lds_cfg ? g_attn_lds_cfg : (cfg ? atoi(cfg) : 0);
+    int c = g_attn_lds_cfg ? g_attn_lds_cfg : (int)lwdetr_knob(KNOB_ATTN_LDS_CFG, 0);
     // a 100-key window = 4 waves of 32 queries. hd 16 (round 4): 128-query workgroups (13 per 1600-query image and head, the last
     // half idle; 4-5 resident per CU) beat 256-query ones (7, the last three quarters idle; 2 per CU): 161 vs 180 us on the bench
     // shape, +1.6 % on config 2 (profiles/r4f_attn_global_workgroup_sizes.txt); hd 32 is indifferent, hd 64 wants the K / V^T reuse
@@ -705,8 +704,7 @@ template <int HD> struct LdsPath<bf16, HD> {
 // only (>= 512 keys), default (2) = also windows of >= 192 keys, 3 = everything >= 64 keys (tests).
 int g_attn_lds_mode = -1;        // lwdetr_attention_tuning(): overrides the environment / default (tests)
 static bool lds_path_applies(const lwdetr_attn_desc& p) {
-    static const char* force = getenv("LWDETR_ATTN_LDS");
-    const int mode = g_attn_lds_mode >= 0 ? g_attn_lds_mode : (force ? atoi(force) : 2);
+    const int mode = g_attn_lds_mode >= 0 ? g_attn_lds_mode : (int)lwdetr_knob(KNOB_ATTN_LDS, 2);
     if (mode == 0) return false;
     // measured (tools/attn_bench.py, us per launch, attn_kernel | LDS ring): 228-key windows hd64 B16: 240 | 131; 100-key windows
     // hd16 B32: 36 | 54, hd32 B64: 113 | 124 - a 100-key sequence is over after two stages, the ring never pays for its start-up
@@ -923,6 +921,7 @@ int launch_win(const lwdetr_attn_desc& p, hipStream_t st) {
 //        barrier the workgroup stores the tile with full 16-byte-per-lane rows - the window's output is ONE contiguous run of
 //        keys x C x 2 bytes (window-major tokens, ldo = C) - instead of 32-byte pieces 2 C bytes apart per (token, head).
 // Arithmetic, masks and rounding points are attn_win_kernel's (the same MFMA sequence per (window, head)); results are bit-identical.
+#ifdef LWDETR_EXPERIMENTS      // see gemm.hip: measured-slower forms are not in the default build
 template <typename T>
 __global__ __launch_bounds__(256) void attn_wtile_kernel(const lwdetr_attn_desc p) {
     constexpr int HD = 16;
@@ -1076,6 +1075,7 @@ int launch_wtile(const lwdetr_attn_desc& p, hipStream_t st) {
     hipLaunchKernelGGL((attn_wtile_kernel<T>), dim3((unsigned)(p.B * p.seqs_per_img)), dim3(256), lds, st, p);
     return lwdetr_check_launch();
 }
+#endif
 
 template <typename T, int HD, int QT>
 int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
@@ -1086,9 +1086,9 @@ int launch_qt(const lwdetr_attn_desc& p, hipStream_t st) {
     const double bytes = 4.0 * nseq * p.heads * p.keys_per_seq * HD * sizeof(T);
     const int kid = p.kind == 0 ? KID_ATTN_WINDOW : (p.kind == 1 ? KID_ATTN_GLOBAL : KID_ATTN_DECODER);
     ProfScope ps(kid, flops, bytes, st);
-    const char* senv = getenv("LWDETR_ATTN_SHORT");         // 0 = the double-buffered form for every length (A-B runs)
+    const bool short_off = lwdetr_knob(KNOB_ATTN_SHORT, 1) == 0;         // LWDETR_ATTN_SHORT=0: the double-buffered form for every length (A-B runs)
     if constexpr (QT == 2 && sizeof(T) == 2) {
-        if (p.keys_per_seq <= 128 && !(senv && atoi(senv) == 0)) {
+        if (p.keys_per_seq <= 128 && !short_off) {
             hipLaunchKernelGGL((attn_kernel<T, HD, QT, true>), grid, dim3(256), 0, st, p);
             return lwdetr_check_launch();
         }
@@ -1108,15 +1108,18 @@ int launch(const lwdetr_attn_desc& p, hipStream_t st) {
         // the dependent MFMA -> max -> exp -> MFMA chain of a (window, head) at 2-3 waves per SIMD, not by its 79 MB of traffic
         // (profiles/r5c_window_attention_hd16.txt). Off unless asked for: LWDETR_ATTN_WTILE=1 (tests keep it bit-identical to the
         // one-wave kernel).
-        const char* wenv = getenv("LWDETR_ATTN_WTILE");
-        const int wmode = wenv ? atoi(wenv) : 0;
+#ifdef LWDETR_EXPERIMENTS
+        const int wmode = (int)lwdetr_knob(KNOB_ATTN_WTILE, 0);
         const int C = p.heads * 16, VLD = ((p.keys_per_seq + 7) & ~7) + 8;
         const size_t lds = ((size_t)C * VLD + (size_t)p.keys_per_seq * (C + 8)) * sizeof(T);
-        if (wmode != 0 && p.keys_per_seq <= 128 && p.sub_stride >= p.keys_per_seq && p.ldo % 8 == 0 && ((size_t)p.out & 15) == 0 &&
+        // (keys % 4 / Tp % 4: the V^T staging moves 4-key pieces and clamps at keys - 4 - advisor r5)
+        if (wmode != 0 && p.keys_per_seq <= 128 && p.keys_per_seq >= 4 && p.keys_per_seq % 4 == 0 && p.Tp % 4 == 0 &&
+            p.sub_stride >= p.keys_per_seq && p.ldo % 8 == 0 && ((size_t)p.out & 15) == 0 &&
             ((size_t)p.VT & 7) == 0 && p.seq_tok_stride % 4 == 0 && lds <= 128 * 1024) {
             const int rc = launch_wtile<T>(p, st);
             if (rc != LWDETR_ERR_UNSUPPORTED) return rc;
         }
+#endif
     }
     if constexpr (sizeof(T) == 2 && (HD == 16 || HD == 32)) {
         // one wave per (sequence, head): sequences of at most 128 keys whose pad rows sit behind the real tokens.
@@ -1124,8 +1127,7 @@ int launch(const lwdetr_attn_desc& p, hipStream_t st) {
         // 108 | 82, large B = 32 fp16 51 | 41; hd 16 (small, B = 16 / 32): 20.4 | 22.0, 32.8 | 36.1 - both forms run their loads
         // and their exp-bound arithmetic in lockstep there and the four-wave form spreads the arithmetic wider.
         // LWDETR_ATTN_WIN: 0 = never, 1 = whenever legal (tests), default = hd 32 only.
-        const char* env = getenv("LWDETR_ATTN_WIN");
-        const int mode = env ? atoi(env) : 2;
+        const int mode = (int)lwdetr_knob(KNOB_ATTN_WIN, 2);
         if (mode != 0 && (mode == 1 || HD == 32) && p.keys_per_seq <= 128 && p.sub_stride >= p.keys_per_seq && p.ldo % 8 == 0 &&
             ((size_t)p.out & 15) == 0 && (long)p.B * p.heads * p.seqs_per_img / 4 < 0x7fffffffL)
             return launch_win<T, HD>(p, st);
@@ -1133,11 +1135,10 @@ int launch(const lwdetr_attn_desc& p, hipStream_t st) {
     if (LdsPath<T, HD>::ok(p) && lds_path_applies(p)) return LdsPath<T, HD>::go(p, st);
     // long sequences: 64 queries per wave (K / V^T fragments amortised over 4 query tiles); short ones keep 32 so a
     // 100-token window still spreads over 4 waves
-    static const char* force = getenv("LWDETR_ATTN_QT");
     // ... and only when that still leaves at least one workgroup per CU (a single image has 84 of them at 64 queries per
     // wave: 25 us per launch against 18 us with 32)
     const long wgs4 = (long)((p.keys_per_seq + 255) / 256) * p.heads * p.B * p.seqs_per_img;
-    const bool qt4 = force ? atoi(force) == 4 : (p.keys_per_seq >= 1024 && HD <= 32 && sizeof(T) == 2 && wgs4 >= 256);
+    const bool qt4 = lwdetr_knob_is_set(KNOB_ATTN_QT) ? lwdetr_knob(KNOB_ATTN_QT, 0) == 4 : (p.keys_per_seq >= 1024 && HD <= 32 && sizeof(T) == 2 && wgs4 >= 256);
     if (qt4) return launch_qt<T, HD, (HD <= 32 ? 4 : 2)>(p, st);
     return launch_qt<T, HD, 2>(p, st);
 }

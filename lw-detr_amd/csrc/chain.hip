@@ -1142,8 +1142,7 @@ extern "C" int lwdetr_row_chain(const lwdetr_chain_desc* d, int dtype, void* hip
     hipStream_t st = (hipStream_t)hip_stream;
     const bool res = d->res != nullptr, qp = d->qpos != nullptr;
     // few rows: the channel-split form (32 rows per workgroup); many rows (or a 2 D-deep first stage): a wave per 32 rows
-    static const char* env_split = getenv("LWDETR_CHAIN_SPLIT_ROWS");
-    const long split_rows = env_split ? atol(env_split) : 16384;      // <= 512 workgroups of 32 rows (two rounds of one per CU); measured: the heads chain of a
+    const long split_rows = lwdetr_knob(KNOB_CHAIN_SPLIT_ROWS, 16384);      // <= 512 workgroups of 32 rows (two rounds of one per CU); measured: the heads chain of a
                                                                        // 16-image launch chain (14 400 rows) is 2-3 % of the step faster in this form (profiles/r4e_*)
     // D = 384: only the channel-split form (its stream is packed k-half-major: the two forms cannot read each other's streams)
     if (d->D == 384) {

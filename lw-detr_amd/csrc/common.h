@@ -153,6 +153,17 @@ struct ProfScope {
     ~ProfScope() { lwdetr_prof_end(s); }
 };
 
+// ---- run-time switches of the launch paths (tuning, A/B runs, tests). Every LWDETR_* variable a launch path looks at is read from the
+// environment ONCE, when the library first needs any of them (prof.hip), into this table - no getenv on a launch path; tests and tools that
+// switch inside one process go through lwdetr_tuning_set (C ABI). A knob that is not set returns the caller's default.
+enum {
+    KNOB_ATTN_LDS_CFG = 0, KNOB_ATTN_LDS, KNOB_ATTN_SHORT, KNOB_ATTN_WTILE, KNOB_ATTN_WIN, KNOB_ATTN_QT, KNOB_CHAIN_SPLIT_ROWS, KNOB_GEMM_BIG,
+    KNOB_GEMM_BIG_BN, KNOB_GEMM_BIG_2WG, KNOB_CONV_PATCH, KNOB_GEMM_TILE, KNOB_GEMM_DMA, KNOB_GEMM_KB, KNOB_GEMM_NST, KNOB_GEMM_PT,
+    KNOB_GEMM_PT_SKEW, KNOB_MLP_SMALL_TT, KNOB_FFN_SPLITS, KNOB_MLP_SMALL, KNOB_VB_GRID, KNOB_VB_GELU16, KNOB_VB_HALF, KNOB_COUNT
+};
+long lwdetr_knob(int id, long dflt);
+bool lwdetr_knob_is_set(int id);
+
 static inline int lwdetr_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LWDETR_OK : LWDETR_ERR_LAUNCH;

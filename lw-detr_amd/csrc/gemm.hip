@@ -1532,11 +1532,17 @@ __device__ __forceinline__ void gemm_big_body(const lwdetr_gemm_desc& d) {
 // (260 -> 312 us, same box: profiles/r5g_*) - and the 4-wave form asks for two workgroups per CU.
 template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const lwdetr_gemm_desc d) { gemm_big_body<T, BN, KB, NST, AMODE, 256, 8>(d); }
+// Round 6: the forms that were built, validated and MEASURED SLOWER (or worth nothing) - the 4-wave / 128-row form (two workgroups per CU, r5a),
+// the LayerNorm-folded epilogue (r5d, r5g), split-K of the 64 x 64 ring kernel (r5e), and attention.hip's LDS window-tile kernel (r5c) - are
+// compiled only with `make TUNE=-DLWDETR_EXPERIMENTS` (their tests skip otherwise; lwdetr_has_experiments()). The default library carries the
+// kernels of the launch plan only: every resident variant was a standing risk of moving the product kernels' register allocation (r5g).
+#ifdef LWDETR_EXPERIMENTS
 template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN>
 __global__ __launch_bounds__(256, 2) void gemm_big4_kernel(const lwdetr_gemm_desc d) { gemm_big_body<T, BN, KB, NST, AMODE, 128, 4>(d); }
 // the 256 x 256 tile with the LayerNorm-folded epilogue (every segment of the launch carries ln_stats): its own kernel, see epilogue_finish_ln
 template <typename T>
 __global__ __launch_bounds__(512) void gemm_big_ln_kernel(const lwdetr_gemm_desc d) { gemm_big_body<T, 256, 64, 2, LWDETR_A_PLAIN, 256, 8, true>(d); }
+#endif
 
 template <typename T, int BN, int KB, int NST, int AMODE = LWDETR_A_PLAIN, int BM = 256, int NW = 8, bool LN = false>
 int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
@@ -1552,17 +1558,23 @@ int launch_big(const lwdetr_gemm_desc& d, hipStream_t st) {
     if (state[dev] == 0)
     {
         const void* fn;
+#ifdef LWDETR_EXPERIMENTS
         if constexpr (LN) fn = (const void*)gemm_big_ln_kernel<T>;
         else if constexpr (NW == 4) fn = (const void*)gemm_big4_kernel<T, BN, KB, NST, AMODE>;
-        else fn = (const void*)gemm_big_kernel<T, BN, KB, NST, AMODE>;
+        else
+#endif
+        fn = (const void*)gemm_big_kernel<T, BN, KB, NST, AMODE>;
         state[dev] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NW == 4 ? 80 * 1024 : 160 * 1024) == hipSuccess ? 1 : -1;
     }
     if (state[dev] < 0) { (void)hipGetLastError(); return LWDETR_ERR_UNSUPPORTED; }
     static_assert(NW == 8 || lds <= 80 * 1024, "two workgroups per CU");
     const long nwg = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+#ifdef LWDETR_EXPERIMENTS
     if constexpr (LN) hipLaunchKernelGGL((gemm_big_ln_kernel<T>), dim3((unsigned)nwg), dim3(512), lds, st, d);
     else if constexpr (NW == 4) hipLaunchKernelGGL((gemm_big4_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(256), lds, st, d);
-    else hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(512), lds, st, d);
+    else
+#endif
+    hipLaunchKernelGGL((gemm_big_kernel<T, BN, KB, NST, AMODE>), dim3((unsigned)nwg), dim3(512), lds, st, d);
     return lwdetr_check_launch();
 }
 
@@ -1588,8 +1600,7 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
     taken = false;
     if constexpr (sizeof(T) != 2 || AMODE == LWDETR_A_PATCH16) return LWDETR_OK;
     else {
-        static const char* env = getenv("LWDETR_GEMM_BIG");
-        const int mode = g_big_mode >= 0 ? g_big_mode : (env ? atoi(env) : 1);
+        const int mode = g_big_mode >= 0 ? g_big_mode : (int)lwdetr_knob(KNOB_GEMM_BIG, 1);
         if (!mode || d.A2 || d.K % 64 != 0 || d.N < 128) return LWDETR_OK;
         if (AMODE == LWDETR_A_CONV3x3 && (d.conv_cin % 64 != 0 || d.a_col0 % 8 != 0 || d.conv_hout > 1024 || d.conv_wout > 1024 ||
                                           d.M / ((long)d.conv_hout * d.conv_wout) >= 2048)) return LWDETR_OK;   // packed pixel coordinates
@@ -1597,8 +1608,7 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
         // ONE column tile instead of two half-empty 128-wide ones); else 128. (Measured: N = 384 as 2 x 192 is 5-20 % slower
         // than 3 x 128 - fewer, fatter tiles on a 2-deep ring - and N = 1152 ties.)
         int bn = d.N % 256 == 0 || d.N > 512 ? 256 : (d.N <= 192 ? 192 : 128);
-        static const char* bn_env = getenv("LWDETR_GEMM_BIG_BN");       // tuning: force the column tile where legal
-        if (bn_env) bn = atoi(bn_env);
+        bn = (int)lwdetr_knob(KNOB_GEMM_BIG_BN, bn);       // tuning: force the column tile where legal
         for (int s = 0; s < d.nseg; ++s)
             if (d.seg[s].n_begin % bn != 0) bn = 128;
         for (int s = 0; s < d.nseg; ++s) if (d.seg[s].n_begin % bn != 0) return LWDETR_OK;
@@ -1606,21 +1616,28 @@ int try_launch_big(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
         if (mode == 1 && !(d.K >= 384 && d.N >= 192 && (d.M >= 16384 || (d.K >= 960 && tiles >= 96)))) return LWDETR_OK;
         const int variant = mode >= 10 ? mode : 0;     // tuning: 32 / 64 = stage depth (ring 4 / 2 deep), 128 = the 4-wave 128-row form
         // 4-wave / 128-row form (two workgroups per CU): LWDETR_GEMM_BIG_2WG = 0 never, 1 where it measured faster (default), 2 whenever legal
-        const char* wg2_env = getenv("LWDETR_GEMM_BIG_2WG");            // read per launch: tests switch it inside one process
-        const int wg2_mode = wg2_env ? atoi(wg2_env) : 1;
+        const int wg2_mode = (int)lwdetr_knob(KNOB_GEMM_BIG_2WG, 1);
         const bool wg2 = variant == 128 || (variant == 0 && (wg2_mode == 2 || (wg2_mode == 1 && big_2wg_pays<AMODE>(d, bn))));
         int rc;
         bool ln = false;
         for (int s_ = 0; s_ < d.nseg; ++s_) ln = ln || d.seg[s_].ln_stats != nullptr;
         if (ln) {       // LayerNorm folded into the GEMM: the 256 x 256 tile's own kernel or nothing (lwdetr_gemm reports the rest as unsupported)
+#ifdef LWDETR_EXPERIMENTS
             if constexpr (AMODE == LWDETR_A_PLAIN) {
                 if (bn == 256) { rc = launch_big<T, 256, 64, 2, LWDETR_A_PLAIN, 256, 8, true>(d, st); taken = rc != LWDETR_ERR_UNSUPPORTED; return taken ? rc : LWDETR_OK; }
             }
+#endif
             return LWDETR_OK;
         }
-        if (bn == 256) rc = wg2 ? launch_big<T, 256, 32, 3, AMODE, 128, 4>(d, st)
-                                : (variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st));
-        else if (bn == 192) rc = wg2 ? launch_big<T, 192, 32, 3, AMODE, 128, 4>(d, st) : launch_big<T, 192, 64, 2, AMODE>(d, st);
+#ifdef LWDETR_EXPERIMENTS
+        if (wg2 && bn == 256) rc = launch_big<T, 256, 32, 3, AMODE, 128, 4>(d, st);
+        else if (wg2 && bn == 192) rc = launch_big<T, 192, 32, 3, AMODE, 128, 4>(d, st);
+        else
+#else
+        if (wg2 && bn != 128) return LWDETR_ERR_UNSUPPORTED;       // the 4-wave form was asked for by name: not in this build
+#endif
+        if (bn == 256) rc = variant == 32 ? launch_big<T, 256, 32, 4, AMODE>(d, st) : launch_big<T, 256, 64, 2, AMODE>(d, st);
+        else if (bn == 192) rc = launch_big<T, 192, 64, 2, AMODE>(d, st);
         else rc = variant == 32 ? launch_big<T, 128, 32, 4, AMODE>(d, st) : launch_big<T, 128, 64, 3, AMODE>(d, st);
         taken = rc != LWDETR_ERR_UNSUPPORTED;          // refused LDS size: the caller launches the ring kernel instead
         return taken ? rc : LWDETR_OK;
@@ -1657,8 +1674,7 @@ int try_launch_conv_patch(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken
     taken = false;
     if constexpr (sizeof(T) != 2) return LWDETR_OK;
     else {
-        const char* env = getenv("LWDETR_CONV_PATCH");       // read per launch: tests switch it inside one process
-        const int mode = env ? atoi(env) : 1;                // 0 = never, 1 = default (N = 128), 2 = whenever legal
+        const int mode = (int)lwdetr_knob(KNOB_CONV_PATCH, 1);     // 0 = never, 1 = default (N = 128), 2 = whenever legal
         if (mode == 0) return LWDETR_OK;
         // N = Cin = 192 (the C = 384 models: 117-153 KB of LDS, one workgroup per CU) measured SLOWER than the 256-row large-tile
         // kernel with its 192-wide column tile (large, B = 32: 16 launches 2.24 vs 1.93 ms per step) - off unless asked for
@@ -1697,9 +1713,8 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
     // epilogue latency is what more, smaller workgroups hide); only the implicit-GEMM 3x3 convolutions (K = 9 Cin, a
     // gathered A panel worth re-using across 128 columns) are faster with 128 x 128.
     bool small = AMODE != LWDETR_A_CONV3x3 || tiles_m * tiles_n < 384;
-    static const char* tile_env = getenv("LWDETR_GEMM_TILE");      // tuning: 1 = 64x64, 2 = 128x64, 3 = 128x128 (where legal)
-    if (tile_env) {
-        const int tsel = atoi(tile_env);
+    if (lwdetr_knob_is_set(KNOB_GEMM_TILE)) {                      // tuning: 1 = 64x64, 2 = 128x64, 3 = 128x128 (where legal)
+        const int tsel = (int)lwdetr_knob(KNOB_GEMM_TILE, 0);
         if (tsel == 1) small = true;
         if (tsel == 2) { small = false; bn64 = true; tiles_n = (d.N + 63) / 64; }
         if (tsel == 3 && !bn64) small = false;
@@ -1727,13 +1742,11 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
             if (d.seg[s_].ln_stats) return LWDETR_ERR_UNSUPPORTED;      // the folded LayerNorm exists in the large-tile kernel's epilogue only
     }
     if constexpr (sizeof(T) == 2) {
-        static const char* env = getenv("LWDETR_GEMM_DMA");
-        const int mode = env ? atoi(env) : 3;
+        const int mode = (int)lwdetr_knob(KNOB_GEMM_DMA, 3);
         if (mode && !d.A2) {
             // 64-deep stages measured equal to 32-deep ones on every GEMM of the network (0.879 vs 0.880 ms per step): the
             // k-loop is not where these short-K GEMMs spend their time. Kept selectable for tuning (LWDETR_GEMM_KB=64).
-            static const char* kb_env = getenv("LWDETR_GEMM_KB");
-            const bool kb64 = kb_env && atoi(kb_env) == 64 && d.K % 64 == 0 && (AMODE != LWDETR_A_CONV3x3 || d.conv_cin % 64 == 0);
+            const bool kb64 = lwdetr_knob(KNOB_GEMM_KB, 32) == 64 && d.K % 64 == 0 && (AMODE != LWDETR_A_CONV3x3 || d.conv_cin % 64 == 0);
             // (An A-panel-resident schedule - the whole K panel of 64 / 128 rows in LDS, column tiles streamed past it - was built
             // and measured in round 2 and removed in round 3: at M = 51200 QKV (N 576, K 192) 51 -> 73 / 106 us, projector 1x1
             // (N 256, K 768) 60 -> 137 us, value projection (N 768, K 256) 62 -> 93 / 124 us. It cuts what a CU pulls in by 2-3x
@@ -1743,11 +1756,12 @@ int launch(const lwdetr_gemm_desc& d, hipStream_t st) {
             else if (small) {
                 // ring depth of the 64 x 64 kernel trades prefetch distance against workgroups per CU (24 KB of LDS at depth 3:
                 // six per CU). Measured on the whole network: depth 4 0.894 ms, depth 3 0.847 ms, depth 2 0.868 ms per step.
-                static const char* nst_env = getenv("LWDETR_GEMM_NST");
-                const int nst = nst_env ? atoi(nst_env) : 3;
+                const int nst = (int)lwdetr_knob(KNOB_GEMM_NST, 3);
                 if (nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 2>), dim3((unsigned)nwg), dim3(256), 0, st, d);
+#ifdef LWDETR_EXPERIMENTS
                 else if (nst == 3 && d.splitk >= 2 && d.splitk_ws && d.K / 32 >= d.splitk)          // round 5: few rows, long K (see gemm_dma_kernel)
                     hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3, 32, true>), dim3((unsigned)(nwg * d.splitk)), dim3(256), 0, st, d);
+#endif
                 else if (nst == 3) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 3>), dim3((unsigned)nwg), dim3(256), 0, st, d);
                 else hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 64, AMODE, 4>), dim3((unsigned)nwg), dim3(256), 0, st, d);
             }
@@ -1777,6 +1791,13 @@ int dispatch_amode(const lwdetr_gemm_desc& d, hipStream_t st) {
 }  // namespace
 
 extern "C" void lwdetr_gemm_tuning(int big_mode) { g_big_mode = big_mode; }
+extern "C" int lwdetr_has_experiments(void) {
+#ifdef LWDETR_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream) {
     if (!desc) return LWDETR_ERR_BAD_ARG;

@@ -469,15 +469,6 @@ __global__ __launch_bounds__(512) void gemm_pt_kernel(const lwdetr_gemm_desc d, 
 }
 
 constexpr int PT_LDS_BYTES = 2 * PT_STAGE * 2 + 2 * PT_NMAX * 4;         // ring + bias / scale vectors = 160 KB
-struct PtTuning { int mode; int skew_ticks; };
-const PtTuning& pt_tuning() {
-    static const PtTuning t = [] {
-        const char* e = getenv("LWDETR_GEMM_PT");       // read once per process: 0 = never, 1 = default shapes, 2 = whenever legal (tests)
-        const char* k = getenv("LWDETR_GEMM_PT_SKEW");  // start-skew window in 10 ns ticks (tuning); default below
-        return PtTuning{e ? atoi(e) : 1, k ? atoi(k) : -1};
-    }();
-    return t;
-}
 int g_pt_mode = -1;
 int g_pt_skew = -1;
 long g_pt_launches = 0;        // launches of the persistent kernel by this process (tests assert which kernel served a shape)
@@ -498,7 +489,7 @@ int pt_launch(const lwdetr_gemm_desc& d, hipStream_t st, bool& taken) {
     const int tiles_n = d.N / PT_BN;
     const long ntiles = ((d.M + PT_BM - 1) / PT_BM) * tiles_n;
     const int grid = (int)(ntiles < ncu[dev] ? ntiles : ncu[dev]);
-    int skew = g_pt_skew >= 0 ? g_pt_skew : pt_tuning().skew_ticks;
+    int skew = g_pt_skew >= 0 ? g_pt_skew : (int)lwdetr_knob(KNOB_GEMM_PT_SKEW, 0);      // LWDETR_GEMM_PT_SKEW: start-skew window in 10 ns ticks (tuning)
     if (skew < 0) skew = 0;
     hipLaunchKernelGGL((gemm_pt_kernel<T>), dim3((unsigned)grid), dim3(512), PT_LDS_BYTES, st, d, tiles_n, (int)ntiles, skew);
     taken = true;
@@ -516,7 +507,7 @@ extern "C" long lwdetr_gemm_pt_count(void) { return g_pt_launches; }
 // power of two >= 8, >= 256 tokens per image - and, by default, the sizes at which the 256-row tile pays at all (gemm.hip: try_launch_big).
 int lwdetr_gemm_pt_try(const lwdetr_gemm_desc& d, int dtype, hipStream_t st, bool& taken) {
     taken = false;
-    const int mode = g_pt_mode >= 0 ? g_pt_mode : pt_tuning().mode;
+    const int mode = g_pt_mode >= 0 ? g_pt_mode : (int)lwdetr_knob(KNOB_GEMM_PT, 1);    // LWDETR_GEMM_PT: 0 = never, 1 = default shapes, 2 = whenever legal
     if (!mode || (dtype != DT_F16 && dtype != DT_BF16)) return LWDETR_OK;
     if (d.a_mode != LWDETR_A_PLAIN || d.A2 || d.K % PT_KB != 0 || d.K < 2 * PT_KB || d.N % PT_BN != 0 || d.N > PT_NMAX || d.M % 8 != 0 || d.M < PT_BM || d.lda % 8 != 0 ||
         ((size_t)d.A & 15) != 0 || ((size_t)d.W & 15) != 0 || (long)64 * d.lda * 2 + 256 >= (1L << 31)) return LWDETR_OK;

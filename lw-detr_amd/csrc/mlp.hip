@@ -812,8 +812,7 @@ int launch_mlp_small_tt(const MlpParams& p, hipStream_t st) {
 }
 template <typename T, bool QKV>
 int launch_mlp_small(const MlpParams& p, hipStream_t st) {
-    static const char* env = getenv("LWDETR_MLP_SMALL_TT");          // tuning: 1 / 2 = tokens tiles per workgroup
-    const int tt = env ? atoi(env) : (p.M <= MLP_SMALL_TT1_MAX_ROWS ? 1 : 2);
+    const int tt = (int)lwdetr_knob(KNOB_MLP_SMALL_TT, p.M <= MLP_SMALL_TT1_MAX_ROWS ? 1 : 2);          // tuning: 1 / 2 = token tiles per workgroup
     if (p.wfrag) return tt == 1 ? launch_mlp_small_tt<T, QKV, 1, true>(p, st) : launch_mlp_small_tt<T, QKV, 2, true>(p, st);
     return tt == 1 ? launch_mlp_small_tt<T, QKV, 1>(p, st) : launch_mlp_small_tt<T, QKV, 2>(p, st);
 }
@@ -878,7 +877,7 @@ int launch_ffn(const MlpParams& p0, int hid, hipStream_t st, int* splits_out) {
     int S = 1;
     while ((long)(nch / S) * 32 > 4 * C && nch % (S * 2) == 0) S *= 2;       // the bias slice lives in the 4C floats of LDS
     if ((long)(nch / S) * 32 > 4 * C) return LWDETR_ERR_UNSUPPORTED;
-    static const int s_max = getenv("LWDETR_FFN_SPLITS") ? atoi(getenv("LWDETR_FFN_SPLITS")) : FFN_MAX_SPLITS;   // tuning
+    const int s_max = (int)lwdetr_knob(KNOB_FFN_SPLITS, FFN_MAX_SPLITS);   // tuning
     while (S * 2 * blocks <= ncu && nch % (S * 2) == 0 && nch / (S * 2) >= 2 && S * 2 <= s_max) S *= 2;
     if (ncu / S > blocks) blocks = ncu / S < q.ntiles ? ncu / S : q.ntiles;   // spare CUs: fewer tiles per workgroup
     q.chunks_per_split = nch / S;
@@ -893,8 +892,7 @@ constexpr long MLP_SMALL_MAX_ROWS = 12800;       // below ~8 images the tile-per
 template <typename T, int C, int TT>
 int launch_mlp(const MlpParams& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && C == 192) {
-        static const char* env = getenv("LWDETR_MLP_SMALL");       // tuning: 0 = never, 1 = always
-        const bool small_ok = p.att && (env ? atoi(env) == 1 : p.M < MLP_SMALL_MAX_ROWS);
+        const bool small_ok = p.att && (lwdetr_knob_is_set(KNOB_MLP_SMALL) ? lwdetr_knob(KNOB_MLP_SMALL, 0) == 1 : p.M < MLP_SMALL_MAX_ROWS);   // tuning: 0 = never, 1 = always
         if (small_ok) return p.wqkv ? launch_mlp_small<T, true>(p, st) : launch_mlp_small<T, false>(p, st);
     }
     if (p.att && p.wqkv) return launch_mlp_p<T, C, TT, true, true>(p, st);

@@ -2,6 +2,9 @@
 // Off by default (zero overhead besides one branch); bench.py switches it on for a dedicated
 // measurement pass so that roofline.achieved comes from the kernel's own launch durations.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -64,3 +67,36 @@ int lwdetr_prof_collect(double* ms, double* flops, double* bytes, long long* cou
 }
 
 }  // extern "C"
+
+// ---- the knob table (common.h): environment variables LWDETR_<NAME>, read once
+namespace {
+const char* kKnobNames[KNOB_COUNT] = {
+    "ATTN_LDS_CFG", "ATTN_LDS", "ATTN_SHORT", "ATTN_WTILE", "ATTN_WIN", "ATTN_QT", "CHAIN_SPLIT_ROWS", "GEMM_BIG", "GEMM_BIG_BN", "GEMM_BIG_2WG",
+    "CONV_PATCH", "GEMM_TILE", "GEMM_DMA", "GEMM_KB", "GEMM_NST", "GEMM_PT", "GEMM_PT_SKEW", "MLP_SMALL_TT", "FFN_SPLITS", "MLP_SMALL", "VB_GRID",
+    "VB_GELU16", "VB_HALF"};
+struct KnobTable {
+    long val[KNOB_COUNT]; bool set[KNOB_COUNT];
+    KnobTable() {
+        for (int i = 0; i < KNOB_COUNT; ++i) {
+            char name[64];
+            snprintf(name, sizeof(name), "LWDETR_%s", kKnobNames[i]);
+            const char* e = getenv(name);
+            set[i] = e != nullptr && *e != 0;
+            // VB_GRID=rounds (whole rounds of one workgroup per CU) is stored as -1
+            val[i] = !set[i] ? 0 : (i == KNOB_VB_GRID && !strcmp(e, "rounds") ? -1 : atol(e));
+        }
+    }
+};
+KnobTable& knobs() { static KnobTable t; return t; }
+}  // namespace
+
+long lwdetr_knob(int id, long dflt) { const KnobTable& t = knobs(); return id >= 0 && id < KNOB_COUNT && t.set[id] ? t.val[id] : dflt; }
+bool lwdetr_knob_is_set(int id) { return id >= 0 && id < KNOB_COUNT && knobs().set[id]; }
+
+extern "C" int lwdetr_tuning_set(const char* name, long value, int is_set) {
+    if (!name) return LWDETR_ERR_BAD_ARG;
+    if (!strncmp(name, "LWDETR_", 7)) name += 7;
+    for (int i = 0; i < KNOB_COUNT; ++i)
+        if (!strcmp(name, kKnobNames[i])) { KnobTable& t = knobs(); t.val[i] = value; t.set[i] = is_set != 0; return LWDETR_OK; }
+    return LWDETR_ERR_BAD_ARG;
+}

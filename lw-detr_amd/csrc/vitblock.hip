@@ -152,7 +152,7 @@ __device__ __forceinline__ unsigned g16_add(unsigned a, unsigned ones) { unsigne
 // the transcendentals of a group's four pairs: low halves first, then high halves - an SDWA write of half a register must not be
 // followed directly by a read of that register (gfx940-family dst_sel forwarding hazard: one wait state; the hazard recognizer does
 // not look inside inline asm), so each register's two instructions sit three instructions apart, and the next tick reads
-// the registers in the same order
+// the registers in the same order; the block ENDS on a wait state, because what follows it is the compiler's choice
 #define VB_G16_TRANS4(OP)                                                                                             \
     asm volatile(OP " %0, %0 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"                          \
                  OP " %1, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"                          \
@@ -161,7 +161,8 @@ __device__ __forceinline__ unsigned g16_add(unsigned a, unsigned ones) { unsigne
                  OP " %0, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
                  OP " %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
                  OP " %2, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
-                 OP " %3, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"                                \
+                 OP " %3, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                          \
+                 "s_nop 0"     /* the instruction hipcc places behind the statement may read %3 (advisor r5) */         \
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 __device__ __forceinline__ void g16_exp2x4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) { VB_G16_TRANS4("v_exp_f16_sdwa"); }
 __device__ __forceinline__ void g16_rcpx4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) { VB_G16_TRANS4("v_rcp_f16_sdwa"); }
@@ -1335,10 +1336,10 @@ int launch_vb(const VbParams& p, hipStream_t st) {
     // Full tiles on as few workgroups as the rows need (a tile costs the same matrix time however many of its 32 NH token slots
     // are filled, so spreading 200 workgroups' rows over 256 buys nothing and takes CUs from whatever runs beside this launch);
     // LWDETR_VB_GRID=rounds restores whole rounds of one workgroup per CU (round-3 measurements), a number forces the grid.
-    static const char* env = getenv("LWDETR_VB_GRID");
+    const long gknob = lwdetr_knob(KNOB_VB_GRID, 0);       // -1 = "rounds"
     long grid = need;
-    if (env && !strcmp(env, "rounds")) grid = (need + s.ncu - 1) / s.ncu * s.ncu;
-    else if (env && atol(env) >= need) grid = atol(env);
+    if (gknob == -1) grid = (need + s.ncu - 1) / s.ncu * s.ncu;
+    else if (gknob >= need) grid = gknob;
     // 8-token units are dealt by floor(): a wave can get one unit more than the average
     while (((p.M / 8 + grid * 4 - 1) / (grid * 4)) * 8 > 32 * NH) ++grid;
     ProfScope ps(KID_VITBLOCK, (16.0 + 2.0 + (QKV ? 6.0 : 0.0)) * p.M * C * C,
@@ -1357,15 +1358,13 @@ int dispatch_vb(const VbParams& p, int C, bool qkv, hipStream_t st) {
     // f16: the GELU on packed f16 pairs (the helpers' comment above; profiles/r5h_block_kernel_packed_f16_gelu.txt: launch -1.5 ... -2.5 %,
     // config 2 / large +0.8 / +0.9 %, the model's mean 16-bit error +0.9 %). LWDETR_VB_GELU16=0 restores the f32-arithmetic form (read per
     // launch: tests switch it); bf16 has no packed arithmetic and keeps it.
-    const char* g16_env = getenv("LWDETR_VB_GELU16");
-    const bool g16 = std::is_same<T, f16>::value && (g16_env ? atoi(g16_env) == 1 : true);
+    const bool g16 = std::is_same<T, f16>::value && lwdetr_knob(KNOB_VB_GELU16, 1) == 1;
     if (C == 192) {
-        const char* half_env = getenv("LWDETR_VB_HALF");
         int dev = 0; (void)hipGetDevice(&dev);
         static int ncu[16] = {};
         if (dev >= 0 && dev < 16 && ncu[dev] == 0) { hipDeviceProp_t prop; ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
         const long cus = dev >= 0 && dev < 16 ? ncu[dev] : 256;
-        const bool half = half_env ? atoi(half_env) == 1 : (p.M + 127) / 128 <= 2 * cus;
+        const bool half = lwdetr_knob_is_set(KNOB_VB_HALF) ? lwdetr_knob(KNOB_VB_HALF, 0) == 1 : (p.M + 127) / 128 <= 2 * cus;
         if (half) {
             if constexpr (sizeof(T) == 2 && std::is_same<T, f16>::value)
                 if (g16) return qkv ? launch_vb<T, 192, 1, true, 2, true>(p, st) : launch_vb<T, 192, 1, false, 2, true>(p, st);

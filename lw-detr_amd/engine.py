@@ -209,8 +209,12 @@ class ForwardPlan:
         # tree on the same box (xlarge 960 x 960 B = 16: 774.0 / 772.2 / 770.5 img/s round-4 tree, 774.0 / 771.2 / 774.2 this tree without the fold,
         # 774.9 / 772.9 / 773.0 with it): the folded epilogue's own kernel runs QKV 290 -> 310 us and fc1 372 -> 399 us, which is what the two
         # 37 -> 19 us statistics passes save (profiles/r5d_*, r5g_*). Opt-in: LWDETR_LN_FOLD=1 (rows >= 16 384: the large-tile kernel's shapes).
+        # The folded epilogue exists in the 256 x 256 large-tile kernel only, which the library takes by itself from 16 384 rows: "1" folds where that
+        # kernel will serve the launch, "2" whatever the row count (tests that force the large-tile kernel with lwdetr_gemm_tuning(2)); and only a
+        # library built with -DLWDETR_EXPERIMENTS carries it (round 6) - otherwise the plan keeps LayerNorm + plain GEMM instead of failing at launch.
         lf_env = os.environ.get("LWDETR_LN_FOLD")
-        ln_fold = (not fused) and self.T != torch.float32 and C % 256 == 0 and lf_env == "1"
+        ln_fold = ((not fused) and self.T != torch.float32 and C % 256 == 0 and (lf_env == "2" or (lf_env == "1" and rows >= 16384))
+                   and bool(K._nat.lib().lwdetr_has_experiments()))
         ln_stats = torch.empty(2, rows, dtype=torch.float32, device=self.dev) if ln_fold else None
         self.ln_fold = ln_fold
         # (Statistics out of the epilogue of the GEMM that PRODUCES the rows were built in four forms and measured a tie at best against this

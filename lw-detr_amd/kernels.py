@@ -39,7 +39,7 @@ def tok_layout(winmajor=False, hp=0, wp=0, twp=0) -> TokLayout:
 def seg(out, n_begin, n_end, *, mode=OUT_LINEAR, ldo=0, bias=None, act=ACT_NONE, scale=1.0, gamma=None, res=None,
         ldres=0, res_mod=0, out2=None, ld2=0, rowmask=None, rowmask_after=False, p0=0, p1=0, p2=0, in_tok=None, out_tok=None,
         out_batch_stride=0, out_row_offset=0, ln_stats=None, ln_colsum=None) -> GemmSeg:
-    """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h). ln_stats (M, 2) f32 + ln_colsum (n) f32:
+    """One output column segment of a GEMM (see lwdetr_gemm_seg in include/lwdetr_hip.h). ln_stats (2, M) f32, PLANAR (mean row, then rstd row) + ln_colsum (n) f32:
     LayerNorm folded into the GEMM (fold_layernorm packs the weights; RowStatsOp produces the planar (2, M) statistics)."""
     s = GemmSeg()
     bias, gamma = _pad8(bias, n_end - n_begin, 0.0), _pad8(gamma, n_end - n_begin, 1.0)
@@ -71,12 +71,19 @@ def splitk_for(M, N, K, dtype, has_a2=False):
     one round of the chip; at least 8 stages of 32 per slice - that was the policy that was measured; it lost (see below), so the automatic
     answer is 1 and LWDETR_GEMM_SPLITK=n forces n slices where legal (tests, tuning)."""
     env = os.environ.get("LWDETR_GEMM_SPLITK")
-    if dtype not in (torch.float16, torch.bfloat16) or has_a2 or K % 32 != 0:
+    if dtype not in (torch.float16, torch.bfloat16) or has_a2 or K % 64 != 0:
         return 1
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
     if env is not None:
-        n = int(env)
-        return n if (n >= 2 and K // 32 >= n) else 1
+        # forced (tests, tuning): only where the launch can take the 64 x 64 ring kernel's split form at all - few rows (the workspace is
+        # tiles x n x 17 KB: at M = 51 200, N = 576 it would be 245 MB per op), a build that carries the kernel, enough k-stages per slice
+        # at either stage depth - and a malformed value means "off", not an exception out of a plan build (advisor r5)
+        try:
+            n = int(env)
+        except ValueError:
+            return 1
+        if not _nat.lib().lwdetr_has_experiments() or M > 3200:
+            return 1
+        return n if (2 <= n <= 16 and K // 64 >= n) else 1
     # Measured (tools/lat_bs1.py, single image, LW-DETR-small as one HIP graph; profiles/r5e_single_image_latency.txt): NOT a gain - the
     # publish / acquire of the slabs (two agent-scope fences + 17 KB per slice through L2) costs what the shorter k-chain saves: 3x3
     # convolutions (K = 1152, 4 slices) 19.2 -> 17.5 us, every K <= 768 GEMM 1.5-2.5 us SLOWER; p50 0.867 ms without, 0.880 with this policy,

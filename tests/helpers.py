@@ -117,12 +117,13 @@ def _oracle_lowp_chunk(job):
     core = O.msda_core
     O.msda_core = lambda value, shapes, loc, aw: core(value.float(), shapes, loc.float(), aw.float()).to(value.dtype)
     try:
+        col = {}
         with _t.no_grad():
-            out = O.forward(sd, cfg, x, forced_topk=_t.from_numpy(np.ascontiguousarray(forced)))
+            out = O.forward(sd, cfg, x, forced_topk=_t.from_numpy(np.ascontiguousarray(forced)), collect=col)
     finally:
         O.msda_core = core
     f = lambda t: t.float().numpy()
-    return {"pred_logits": f(out["pred_logits"]), "pred_boxes": f(out["pred_boxes"]),
+    return {"pred_logits": f(out["pred_logits"]), "pred_boxes": f(out["pred_boxes"]), "enc_class_max": f(col["enc.class_max"]),
             "enc_logits": f(out["enc_outputs"]["pred_logits"]), "enc_boxes": f(out["enc_outputs"]["pred_boxes"]),
             "aux_logits": np.stack([f(a["pred_logits"]) for a in out["aux_outputs"]], 1),
             "aux_boxes": np.stack([f(a["pred_boxes"]) for a in out["aux_outputs"]], 1)}

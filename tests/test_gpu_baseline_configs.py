@@ -61,7 +61,9 @@ _BOUNDS = {
     "large_b32_fp16": dict(logit_max=0.083, box_max=0.0074, logit_mean=0.0052, overlap=0.99, gap=0.0098, found=0.98, score=0.007, px=2.0),
     # round 5: gap / score re-measured at 0.0042-0.0052 / 0.0040-0.0060 on three runs (with and without the opt-in LayerNorm fold; every
     # averaged and calibrated figure identical: logit_mean 0.00321-0.00323, ours / reference 16-bit 0.27): they are maxima over 4800 ranks /
-    # 1600 detections and follow which near-ties reorder - bounds = 1.5x the largest measurement (profiles/r5d_*)
+    # 1600 detections and follow which near-ties reorder - bounds = 1.5x the largest measurement (profiles/r5d_*). Round 6: these two absolute
+    # bounds are a regression fence only; the oracle-derived bound for both quantities is the calibrated one at the end of the test
+    # (topk_score_gap / score_slot_max <= 1.5x the reference's own 16-bit arithmetic on the same images), for every configuration.
     "xlarge960_b16_fp16": dict(logit_max=0.11, box_max=0.0178, logit_mean=0.0064, overlap=0.99, gap=0.0078, found=0.98, score=0.009, px=2.0),
 }
 
@@ -147,6 +149,18 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
              "box_mean": float(np.abs(low["pred_boxes"] - exp["pred_boxes"][sel]).mean())}
     ours16 = {"logit_max": float(max(dl[sel].max(), del_[sel].max())), "logit_mean": float(dl[sel].mean()),
               "box_max": float(max(db[sel].max(), deb[sel].max())), "box_mean": float(db[sel].mean())}
+    # Round 6: the two figures that had only absolute bounds - the rank-wise score gap of the two-stage selection and the
+    # detection score error - calibrated the same way. Selection: the 16-bit reference arithmetic's OWN free selection (top-k of its class maxima)
+    # judged with the fp32 oracle's scores, against ours on the same images. Scores: sigmoid of the final logits slot by slot (the selection is
+    # forced, so slots correspond) - what PostProcess turns into detection scores, without the matching step's twin-detection noise.
+    nq_ = cfg.num_queries
+    low_idx = np.argsort(-low["enc_class_max"], axis=1, kind="stable")[:, :nq_]
+    srt = lambda pick: np.sort(np.take_along_axis(ref_sc[sel], pick, 1), 1)
+    ref16["topk_score_gap"] = float(np.abs(srt(low_idx) - srt(ref_idx[sel])).max())
+    ours16["topk_score_gap"] = float(np.abs(srt(ours[sel]) - srt(ref_idx[sel])).max())
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    ref16["score_slot_max"] = float(np.abs(sig(low["pred_logits"]) - sig(exp["pred_logits"][sel])).max())
+    ours16["score_slot_max"] = float(np.abs(sig(out["pred_logits"].float().cpu().numpy()[sel]) - sig(exp["pred_logits"][sel])).max())
     # per launch chain: the same ratio on the images of each half batch (a chain-1-only defect must not hide in the pooled figure)
     per_chain = {}
     for ci, part in enumerate((sel[sel < half], sel[sel >= half])):
@@ -171,8 +185,11 @@ def test_baseline_config_parity(name, size, res, batch, dtype):
     # pixel away may pair with its neighbour's score - that is what the closest-score pairing above removes, not a kernel error)
     assert m["score_nearest_box_p999"] < b["score"], m
     # calibrated: no worse than 1.5x what the reference's own arithmetic costs in this dtype, on the same images
-    for k in ("logit_max", "logit_mean", "box_max", "box_mean"):
+    for k in ("logit_max", "logit_mean", "box_max", "box_mean", "score_slot_max"):
         assert ours16[k] <= 1.5 * ref16[k], (k, ours16, ref16)
+    # the selection gap is a maximum over a few thousand ranks of which near-ties reorder: 1.5x the reference arithmetic's own, with a floor of one
+    # 16-bit ulp of a class logit around -2 (a gap below that is a tie in the dtype)
+    assert ours16["topk_score_gap"] <= max(1.5 * ref16["topk_score_gap"], 2e-3), (ours16, ref16)
     for ck, cv in per_chain.items():
         assert cv["ours_logit_max"] <= 1.5 * cv["ref_logit_max"], (ck, cv)
     if "aux_logit_max" in m:

@@ -21,6 +21,14 @@ def _rand(*shape, dtype=torch.float32, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(_dev())
 
 
+def _need_experiments():
+    """The measured-slower opt-in kernels (4-wave large-tile form, LayerNorm-folded epilogue, split-K, LDS window tiles) are compiled only with
+    `make TUNE=-DLWDETR_EXPERIMENTS` since round 6; their tests run against such a build (LWDETR_HIP_LIB) and skip on the default library."""
+    from lwdetr_amd import _native
+    if not _native.lib().lwdetr_has_experiments():
+        pytest.skip("kernel variant not in the default build (make TUNE=-DLWDETR_EXPERIMENTS)")
+
+
 def _relerr(a, b):
     a, b = a.float(), b.float()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
@@ -133,12 +141,14 @@ def test_gemm_conv3x3(dtype, stride, winmajor):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("stride,winmajor,cout", [(1, False, 192), (2, True, 384), (1, True, 128), (2, False, 256)])
 @pytest.mark.parametrize("wg2", ["0", "2"])
-def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, wg2, big_gemm, monkeypatch):
+def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, wg2, big_gemm, monkeypatch, knobs):
     """The implicit-GEMM 3x3 view on the 256-row large-tile kernel (column tiles 192 / 128 / 256), zero padding at the image
     border, stride 1 | 2, raster and window-major inputs, a channel window inside wider rows - vs F.conv2d. wg2 = 2: the 4-wave
     128-row form of the kernel (column tiles 256 / 192) wherever it is legal."""
     from lwdetr_amd import kernels as K
-    monkeypatch.setenv("LWDETR_GEMM_BIG_2WG", wg2)
+    if wg2 == "2":
+        _need_experiments()
+    knobs.set("GEMM_BIG_2WG", wg2)
     b, hp, wp, cin, ctot, col0 = 3, 24, 32, 128, 320, 64
     x = _rand(b, hp, wp, ctot, dtype=dtype, seed=1)
     w = _rand(cout, cin, 3, 3, dtype=dtype, scale=(9 * cin) ** -0.5, seed=2)
@@ -158,7 +168,7 @@ def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, wg2, big_gemm, m
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("b,hp,wp,c", [(2, 40, 40, 128), (3, 10, 13, 128), (2, 20, 20, 192), (1, 80, 80, 192), (5, 7, 9, 192), (1, 60, 60, 128)])
-def test_gemm_conv3x3_patch_resident(dtype, b, hp, wp, c, monkeypatch):
+def test_gemm_conv3x3_patch_resident(dtype, b, hp, wp, c, monkeypatch, knobs):
     """The patch-resident 3x3 convolution (stride 1, raster rows, N = Cin: the C2f bottleneck convolutions) vs F.conv2d in fp64
     and vs the implicit-GEMM ring kernel it replaces: image borders, 128-pixel tiles that straddle images (10 x 13, 7 x 9), a
     ragged last tile, a channel window inside wider rows on both sides (the C2f concat buffer), the widest patch that fits."""
@@ -169,7 +179,7 @@ def test_gemm_conv3x3_patch_resident(dtype, b, hp, wp, c, monkeypatch):
     bias = _rand(c, seed=3)
     outs = []
     for patch in ("2", "0"):
-        monkeypatch.setenv("LWDETR_CONV_PATCH", patch)
+        knobs.set("CONV_PATCH", patch)
         out = torch.full((b * hp * wp, ctot), 3.0, dtype=dtype, device=_dev())
         K.GemmOp(x.reshape(-1, ctot), w.permute(0, 2, 3, 1).reshape(c, -1).contiguous(), b * hp * wp, c, 9 * c,
                  [K.seg(out[:, ocol:], 0, c, ldo=ctot, bias=bias, act=K.ACT_SILU)], lda=ctot, a_mode=K.A_CONV3x3,
@@ -302,7 +312,7 @@ def _attention_case(dtype, hd, geom, cfg):
 @pytest.mark.parametrize("hd", [16, 32])
 @pytest.mark.parametrize("twp,tw,spi,b,heads", [(100, 100, 16, 2, 3), (28, 25, 16, 1, 3), (128, 126, 3, 1, 3), (36, 36, 16, 1, 2), (8, 5, 5, 1, 1),
                                                  (64, 64, 16, 1, 4), (100, 97, 16, 1, 2)])
-def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkeypatch):
+def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkeypatch, knobs):
     """attn_win_kernel (sequences of <= 128 keys, one wave per (sequence, head)) vs the fp32 formulation and vs attn_kernel:
     pad rows behind the real tokens, ragged key / query tiles, a partially filled last workgroup, 8 keys."""
     from lwdetr_amd import kernels as K
@@ -314,9 +324,9 @@ def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkey
     qs = (q.float() * K.attention_scale(hd)).to(dtype)
     vt = v.transpose(2, 3).contiguous()
     outs = []
-    monkeypatch.setenv("LWDETR_ATTN_WTILE", "0")
+    knobs.set("ATTN_WTILE", "0")
     for win in ("1", "0"):
-        monkeypatch.setenv("LWDETR_ATTN_WIN", win)
+        knobs.set("ATTN_WIN", win)
         out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())
         K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd, seqs_per_img=spi, seq_tok_stride=twp,
                  keys_per_seq=twp, sub_stride=twp, sub_len=tw, kind=0)()
@@ -329,10 +339,11 @@ def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkey
     e_old = ((outs[1] - ref)[:, :, valid]).abs().max().item()
     assert e_new < {torch.float16: 6e-3, torch.bfloat16: 4e-2}[dtype] and e_new < 1.5 * e_old + 1e-4, (e_new, e_old)
     assert torch.isfinite(outs[0]).all()              # pad rows are written too (finite)
-    if hd == 16:
+    from lwdetr_amd import _native
+    if hd == 16 and _native.lib().lwdetr_has_experiments():
         # round 5: the window-tile kernel (one workgroup per (image, window), V^T and the output tile through LDS) runs the same MFMA
         # sequence per (window, head) as the one-wave kernel: bit-identical, pad rows included
-        monkeypatch.setenv("LWDETR_ATTN_WTILE", "1")
+        knobs.set("ATTN_WTILE", "1")
         out = torch.zeros(b * tp, heads * hd, dtype=dtype, device=_dev())
         K.AttnOp(qs, k, vt, out, B=b, heads=heads, hd=hd, Tp=tp, ldo=heads * hd, seqs_per_img=spi, seq_tok_stride=twp,
                  keys_per_seq=twp, sub_stride=twp, sub_len=tw, kind=0)()
@@ -344,7 +355,7 @@ def test_attention_one_wave_per_window(dtype, hd, twp, tw, spi, b, heads, monkey
         vt2 = v2.transpose(2, 3).contiguous()
         res = []
         for wt in ("1", "0"):
-            monkeypatch.setenv("LWDETR_ATTN_WTILE", wt)
+            knobs.set("ATTN_WTILE", wt)
             o2 = torch.full((b2 * tp, h2 * hd + 64), 7.0, dtype=dtype, device=_dev())
             K.AttnOp(q2, k2, vt2, o2, B=b2, heads=h2, hd=hd, Tp=tp, ldo=h2 * hd + 64, seqs_per_img=spi, seq_tok_stride=twp,
                      keys_per_seq=twp, sub_stride=twp, sub_len=tw, kind=0)()
@@ -375,6 +386,8 @@ def test_gemm_large_tile_kernel(dtype, mnk, depth):
     """gemm_big_kernel (256 x 256 / 256 x 128 tiles, 32x32x16 MFMA, DMA ring of 32- and 64-deep stages; depth 128 = the 4-wave
     128 x 256 / 128 x 192 form) vs torch: bias, GELU, LayerScale + residual epilogue; ragged M and N tails."""
     from lwdetr_amd import _native, kernels as K
+    if depth == 128:
+        _need_experiments()
     m, n, k = mnk
     x = _rand(m, k, dtype=dtype, seed=1)
     w = _rand(n, k, dtype=dtype, scale=k ** -0.5, seed=2)
@@ -504,10 +517,12 @@ def test_gemm_persistent_tile_kernel_head_layouts(dtype, b, tp):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("hd", [64, 32, 16])
 @pytest.mark.parametrize("wg2", ["0", "2"])
-def test_gemm_large_tile_kernel_head_layouts(dtype, hd, wg2, big_gemm, monkeypatch):
+def test_gemm_large_tile_kernel_head_layouts(dtype, hd, wg2, big_gemm, monkeypatch, knobs):
     """QKV of the C = 768 / 384 / 192 models through the large-tile kernel (column tiles 256 / 192 / 192; wg2 = 2: its 4-wave
     128-row form): HEADS (q, k) and HEADS_T (V^T, swapped MFMA operands)."""
-    monkeypatch.setenv("LWDETR_GEMM_BIG_2WG", wg2)
+    if wg2 == "2":
+        _need_experiments()
+    knobs.set("GEMM_BIG_2WG", wg2)
     _check_qkv_layouts(dtype, hd, 4, 1600)
     _check_qkv_layouts(dtype, hd, 1, 1000)          # ragged last row tile (1000 = 7 x 128 + 104)
 
@@ -520,6 +535,7 @@ def test_gemm_with_layernorm_folded_in(dtype, m, c, mode):
     HEADS_T segments, scaled q) and fc1-shaped (GELU) outputs, rows with a large common offset (mean >> std: the cancellation case),
     ragged M. The fold lives in the 256 x 256 large-tile kernel's own epilogue (gemm_big_ln_kernel): mode 2 / 64 force that kernel, -1 at
     16 384 rows takes it by itself; shapes it does not serve are refused (last lines)."""
+    _need_experiments()
     from lwdetr_amd import _native, kernels as K
     heads = 12 if c % 12 == 0 else 8
     hd = c // heads
@@ -576,6 +592,7 @@ def test_gemm_split_k_few_rows(dtype, splits):
     convolution (implicit GEMM, SiLU), a 1x1 convolution into a TOKMAP destination shape, a decoder Linear with residual + ragged M / N.
     Against torch fp32 and against the unsplit launch; repeated launches are bit-identical (the sum does not depend on who arrives last) and
     leave the arrival counters at zero."""
+    _need_experiments()
     from lwdetr_amd import kernels as K
     # (a) 3x3 convolution, 40 x 40 pixels, 128 -> 128 channels inside wider rows
     b, hp, wp, c, ctot, col0 = 1, 40, 40, 128, 256, 64
@@ -801,7 +818,7 @@ def test_vit_block_few_fragment_major_weights(dtype, m, tp):
                                           (384, 12, 25600, 1600), (384, 12, 12816, 4272), (192, 6, 13000, 1000)])
 @pytest.mark.parametrize("half", ["0", "1"])
 @pytest.mark.parametrize("gelu16", ["0", "1"])
-def test_vit_block(dtype, c, heads, m, tp, half, gelu16, monkeypatch):
+def test_vit_block(dtype, c, heads, m, tp, half, gelu16, monkeypatch, knobs):
     """gelu16 = 1: the GELU on packed f16 pairs (the f16 default since round 5, LWDETR_VB_GELU16=0|1, f16 only; tests/vitblock_sim.py:gelu_vb16_packed) - same bounds
     against the erf-GELU fp32 formulation, different bits from the f32-arithmetic form and within 2e-3 of it. half = 1: the C = 192 form with 32 tokens per wave / two workgroups per CU (round 5; the default while all workgroups of a launch
     are resident at once), half = 0: 64 tokens per wave. lwdetr_vit_block (attention projection + LayerScale + residual, norm2 -> fc1 -> GELU -> fc2 -> LayerScale -> residual, and
@@ -813,8 +830,8 @@ def test_vit_block(dtype, c, heads, m, tp, half, gelu16, monkeypatch):
         pytest.skip("the half-tile form exists for C = 192 only")
     if gelu16 == "1" and dtype != torch.float16:
         pytest.skip("packed-f16 GELU: f16 only")
-    monkeypatch.setenv("LWDETR_VB_HALF", half)
-    monkeypatch.setenv("LWDETR_VB_GELU16", gelu16)
+    knobs.set("VB_HALF", half)
+    knobs.set("VB_GELU16", gelu16)
     hd = c // heads
     assert K.vit_block_supported(c, dtype, hd)
     x = _rand(m, c, dtype=dtype, seed=1) * 2 + 0.3
@@ -868,10 +885,10 @@ def test_vit_block(dtype, c, heads, m, tp, half, gelu16, monkeypatch):
         K.VitBlockOp(xx2, att, stream, vec, m, c, 1e-6, **kw)()
         assert torch.equal(xx2, xx)
         if gelu16 == "1":                        # the switch is read per launch: the same op with the f32-arithmetic GELU
-            monkeypatch.setenv("LWDETR_VB_GELU16", "0")
+            knobs.set("VB_GELU16", "0")
             xx3 = x.clone()
             K.VitBlockOp(xx3, att, stream, vec, m, c, 1e-6, **kw)()
-            monkeypatch.setenv("LWDETR_VB_GELU16", "1")
+            knobs.set("VB_GELU16", "1")
             assert not torch.equal(xx3, xx) and _relerr(xx3, xx) < 2e-3, _relerr(xx3, xx)
     w1p, b1p, w2p = K.pack_mlp_weights(w1, b1, w2, lw, lb, dtype, proj=True)
     xo = x.clone()
@@ -880,7 +897,7 @@ def test_vit_block(dtype, c, heads, m, tp, half, gelu16, monkeypatch):
 
 
 @pytest.mark.parametrize("gelu", ["f32", "packed_f16"])
-def test_vit_block_rounding_points_fp64(gelu, monkeypatch):
+def test_vit_block_rounding_points_fp64(gelu, monkeypatch, knobs):
     """The 16-bit block kernel against an fp64 evaluation of the same arithmetic with the kernel's rounding points (16-bit
     inputs / weights, x1 and the output rounded to f16, f32 accumulation otherwise): the benchmarked kernel itself meets the
     1e-3 bar of the fp32 parity gate when its inputs are exactly representable. gelu = packed_f16: the f16
@@ -888,7 +905,7 @@ def test_vit_block_rounding_points_fp64(gelu, monkeypatch):
     within an ulp of the model's correctly rounded ones, hence the wider bounds)."""
     from lwdetr_amd import kernels as K
     from tests.vitblock_sim import gelu_vb16, gelu_vb16_packed
-    monkeypatch.setenv("LWDETR_VB_GELU16", "1" if gelu == "packed_f16" else "0")
+    knobs.set("VB_GELU16", "1" if gelu == "packed_f16" else "0")
     if gelu == "packed_f16":
         gelu_vb16 = gelu_vb16_packed                                    # noqa: F811
     c, m, dtype = 192, 12800, torch.float16

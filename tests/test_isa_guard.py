@@ -64,7 +64,7 @@ def test_packed_f16_gelu_kernels_carry_only_straight_forms():
     op_sel question of section 5d never arises. Checked on the built object: every G16 instantiation holds packed-f16 arithmetic and SDWA
     transcendentals, none of its packed-f16 instructions carries an op_sel / op_sel_hi / neg modifier, every SDWA transcendental selects the
     same word for source and destination and preserves the other half, and a register's two SDWA writes are never adjacent (dst_sel
-    forwarding hazard: the hazard recognizer does not look inside inline asm)."""
+    forwarding hazard: the hazard recognizer does not look inside inline asm), and every block of them ends on an s_nop."""
     import re
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_isa
@@ -93,6 +93,11 @@ def test_packed_f16_gelu_kernels_carry_only_straight_forms():
         for a, b in zip(ins, ins[1:]):
             if a.startswith(("v_exp_f16_sdwa", "v_rcp_f16_sdwa")) and b.startswith(("v_exp_f16_sdwa", "v_rcp_f16_sdwa")):
                 assert a.split()[1] != b.split()[1], (name, a, b)          # same destination register back to back
+        # round 6 (advisor r5): what follows a block's LAST SDWA write is the compiler's choice and may read its destination - the block
+        # therefore ends on a wait state of its own: every run of SDWA transcendentals is followed by an s_nop, never directly by a reader
+        for a, b in zip(ins, ins[1:]):
+            if a.startswith(("v_exp_f16_sdwa", "v_rcp_f16_sdwa")) and not b.startswith(("v_exp_f16_sdwa", "v_rcp_f16_sdwa")):
+                assert b.startswith("s_nop"), (name, a, b)
     # the kernels that existed before do not carry the packed-f16 forms (own instantiations: profiles/r5g_* is why)
     old = {k: v for k, v in funcs.items() if "vitblock_kernel" in k and k not in g16}
     assert len(old) == 12 and not any(re.match(r"v_(exp|rcp)_f16_sdwa\b", i) for v in old.values() for i in v)
