@@ -124,6 +124,13 @@ typedef struct {
 } lwdetr_gemm_desc;
 
 int lwdetr_gemm(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
+/* Few-row form (round 6; the single-image latency path): the same descriptor as lwdetr_gemm with W FRAGMENT-MAJOR - [N / 16][K / 32][16][32],
+ * lwdetr_amd.kernels.pack_frag16 of the (N, K) matrix lwdetr_gemm takes. A workgroup owns 16 rows x 128 columns, a wave loads the MFMA fragments of a
+ * third of the contraction straight from L2 before it multiplies them: no LDS ring, no barriers - the six 3x3 convolutions of the projector
+ * (models/backbone/projector.py:101-132) at one 640 x 640 image 19.3 -> ~9 us each. Serves: 16-bit, M <= 8192, a_mode PLAIN or CONV3x3 (raster rows,
+ * stride 1 | 2, Cin in {128, 192}), K % 32 == 0, N % 16 == 0, ONE LINEAR segment (bias, activation, scale, gamma, residual, second destination;
+ * no row mask); LWDETR_ERR_UNSUPPORTED otherwise. Same arithmetic as lwdetr_gemm up to the f32 summation order of the contraction. */
+int lwdetr_gemm_few(const lwdetr_gemm_desc* desc, int dtype, void* hip_stream);
 /* Row statistics of x (M, C) for the LayerNorm-folded GEMM: stats[m] = mean, stats[M + m] = 1 / sqrt(var + eps) (planar - interleaved pairs made
  * hipcc broadcast the high half of a register pair into packed-f32 epilogue arithmetic, the instruction form tools/check_isa.py refuses),
  * two-pass f32 on the stored values -
@@ -372,7 +379,7 @@ int lwdetr_resize_normalize(const lwdetr_resize_image* images, int B, int max_he
 
 /* ---- run-time switches (tuning, A/B runs, tests). Every environment variable LWDETR_<NAME> that a launch path of this library looks at
  * (kernel choices and shapes: ATTN_LDS, ATTN_LDS_CFG, ATTN_SHORT, ATTN_WTILE, ATTN_WIN, ATTN_QT, CHAIN_SPLIT_ROWS, GEMM_BIG, GEMM_BIG_BN, GEMM_BIG_2WG,
- * CONV_PATCH, GEMM_TILE, GEMM_DMA, GEMM_KB, GEMM_NST, GEMM_PT, GEMM_PT_SKEW, MLP_SMALL_TT, FFN_SPLITS, MLP_SMALL, VB_GRID, VB_GELU16, VB_HALF) is read
+ * CONV_PATCH, GEMM_TILE, GEMM_DMA, GEMM_KB, GEMM_NST, GEMM_PT, GEMM_PT_SKEW, MLP_SMALL_TT, FFN_SPLITS, MLP_SMALL, VB_GRID, VB_GELU16, VB_HALF, GEMM_FEW_WAVES) is read
  * ONCE per process into a table; no launch calls getenv. lwdetr_tuning_set overrides (is_set != 0) or clears (is_set == 0: back to the built-in
  * default, not to the environment) one entry by name, with or without the LWDETR_ prefix; LWDETR_ERR_BAD_ARG for an unknown name. Process-wide,
  * not synchronised with launches in flight on other threads. Results never depend on a switch beyond f32 summation order, except VB_GELU16

@@ -85,6 +85,7 @@ def lib():
         l.lwdetr_msda_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
         l.lwdetr_msda_fused_forward.argtypes = [vp, vp, vp, vp, lg, i, vp, vp, vp, i, i, i, i, i, i, i, i, vp]
         l.lwdetr_gemm.argtypes = [C.POINTER(GemmDesc), i, vp]
+        l.lwdetr_gemm_few.argtypes = [C.POINTER(GemmDesc), i, vp]
         l.lwdetr_attention.argtypes = [C.POINTER(AttnDesc), i, vp]
         l.lwdetr_gemm_tuning.argtypes = [i]
         l.lwdetr_gemm_tuning.restype = None

@@ -159,7 +159,7 @@ struct ProfScope {
 enum {
     KNOB_ATTN_LDS_CFG = 0, KNOB_ATTN_LDS, KNOB_ATTN_SHORT, KNOB_ATTN_WTILE, KNOB_ATTN_WIN, KNOB_ATTN_QT, KNOB_CHAIN_SPLIT_ROWS, KNOB_GEMM_BIG,
     KNOB_GEMM_BIG_BN, KNOB_GEMM_BIG_2WG, KNOB_CONV_PATCH, KNOB_GEMM_TILE, KNOB_GEMM_DMA, KNOB_GEMM_KB, KNOB_GEMM_NST, KNOB_GEMM_PT,
-    KNOB_GEMM_PT_SKEW, KNOB_MLP_SMALL_TT, KNOB_FFN_SPLITS, KNOB_MLP_SMALL, KNOB_VB_GRID, KNOB_VB_GELU16, KNOB_VB_HALF, KNOB_COUNT
+    KNOB_GEMM_PT_SKEW, KNOB_MLP_SMALL_TT, KNOB_FFN_SPLITS, KNOB_MLP_SMALL, KNOB_VB_GRID, KNOB_VB_GELU16, KNOB_VB_HALF, KNOB_GEMM_FEW_WAVES, KNOB_COUNT
 };
 long lwdetr_knob(int id, long dflt);
 bool lwdetr_knob_is_set(int id);

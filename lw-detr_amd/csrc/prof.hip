@@ -73,7 +73,7 @@ namespace {
 const char* kKnobNames[KNOB_COUNT] = {
     "ATTN_LDS_CFG", "ATTN_LDS", "ATTN_SHORT", "ATTN_WTILE", "ATTN_WIN", "ATTN_QT", "CHAIN_SPLIT_ROWS", "GEMM_BIG", "GEMM_BIG_BN", "GEMM_BIG_2WG",
     "CONV_PATCH", "GEMM_TILE", "GEMM_DMA", "GEMM_KB", "GEMM_NST", "GEMM_PT", "GEMM_PT_SKEW", "MLP_SMALL_TT", "FFN_SPLITS", "MLP_SMALL", "VB_GRID",
-    "VB_GELU16", "VB_HALF"};
+    "VB_GELU16", "VB_HALF", "GEMM_FEW_WAVES"};
 struct KnobTable {
     long val[KNOB_COUNT]; bool set[KNOB_COUNT];
     KnobTable() {

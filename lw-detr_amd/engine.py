@@ -410,16 +410,22 @@ class ForwardPlan:
                     kcat = ntap * C
                 ops.append(GemmOp(cat, w1, M, 2 * c, kcat, [seg(ycat, 0, 2 * c, ldo=5 * c, bias=b1, act=ACT_SILU)]))
             tmp = z(M, c)
+            # round 6: at one or two images the 3x3 convolutions run on the few-row kernel (fragment-major weights straight from L2, no LDS ring)
+            few = K.gemm_few_supported(self.T, M, A_CONV3x3, c)
+            conv_cls = K.GemmFewOp if few else GemmOp
             for m in range(3):
                 wa, ba = pw.convx(f"{st}.m.{m}.cv1")
                 wb, bb = pw.convx(f"{st}.m.{m}.cv2")
+                if few:
+                    wa = pw.custom(f"{st}.m.{m}.cv1.frag", lambda wa=wa: K.pack_frag16(wa))
+                    wb = pw.custom(f"{st}.m.{m}.cv2.frag", lambda wb=wb: K.pack_frag16(wb))
                 dst = ycat[:, (2 + m) * c:]
-                ops.append(GemmOp(ycat, wa, M, c, 9 * c, [seg(tmp, 0, c, ldo=c, bias=ba, act=ACT_SILU)], lda=5 * c,
-                                  a_mode=A_CONV3x3, a_tok=ras, conv_cin=c, conv_stride=1, a_col0=(1 + m) * c,
-                                  conv_hout=hl, conv_wout=wl))
-                ops.append(GemmOp(tmp, wb, M, c, 9 * c, [seg(dst, 0, c, ldo=5 * c, bias=bb, act=ACT_SILU)], lda=c,
-                                  a_mode=A_CONV3x3, a_tok=ras, conv_cin=c, conv_stride=1, a_col0=0, conv_hout=hl,
-                                  conv_wout=wl, keep=(dst,)))
+                ops.append(conv_cls(ycat, wa, M, c, 9 * c, [seg(tmp, 0, c, ldo=c, bias=ba, act=ACT_SILU)], lda=5 * c,
+                                    a_mode=A_CONV3x3, a_tok=ras, conv_cin=c, conv_stride=1, a_col0=(1 + m) * c,
+                                    conv_hout=hl, conv_wout=wl))
+                ops.append(conv_cls(tmp, wb, M, c, 9 * c, [seg(dst, 0, c, ldo=5 * c, bias=bb, act=ACT_SILU)], lda=c,
+                                    a_mode=A_CONV3x3, a_tok=ras, conv_cin=c, conv_stride=1, a_col0=0, conv_hout=hl,
+                                    conv_wout=wl, keep=(dst,)))
             if self.use_chain and self.L == 1 and K.enc_chain_supported(d, self.T, k5=5 * c) and os.environ.get("LWDETR_CHAIN_FRONT", "1") != "0":
                 self.chain_front = dict(ycat=ycat, k5=5 * c, cv2=st + ".cv2", ln=f"{pre}.stages.{li}.1", npix=npix, lsi=self.lsi[li], M=M)
                 continue

@@ -120,11 +120,45 @@ class GemmOp:
         self._keep = (A, A2, W, segs, ws) + tuple(keep)
         self._fn = _nat.lib().lwdetr_gemm
         self._ref = C.byref(d)
+        # few rows (one or two images), one plain LINEAR segment: the few-row kernel on a fragment-major copy of W (made here, once per plan)
+        sg0 = segs[0]
+        if (type(self) is GemmOp and len(segs) == 1 and A2 is None and nsplit < 2 and sg0.mode == OUT_LINEAR and not sg0.rowmask and not sg0.ln_stats
+                and sg0.res_mod == 0 and N_ % 16 == 0 and K % 32 == 0 and a_mode == A_PLAIN and d.lda % 8 == 0 and sg0.ldo % 4 == 0
+                and gemm_few_supported(A.dtype, M, A_PLAIN, 0, K)):
+            Wf = pack_frag16(W)
+            d.W = _ptr(Wf)
+            self._keep = self._keep + (Wf,)
+            self._fn = _nat.lib().lwdetr_gemm_few
 
     def __call__(self, stream=None):
         rc = self._fn(self._ref, self.dtype, stream if stream is not None else _nat.stream_ptr())
         if rc:
             _nat.check(rc, f"gemm M={self.desc.M} N={self.desc.N} K={self.desc.K} a_mode={self.desc.a_mode}")
+
+
+GEMM_FEW_MAX_ROWS = 3200        # one or two 640 x 640 images (see gemm_few_supported)
+
+
+def gemm_few_supported(dtype, M, a_mode=A_PLAIN, conv_cin=0, K=0) -> bool:
+    """The launch-plan choice for lwdetr_gemm_few (the few-row kernel on fragment-major weights): the 3x3 convolutions of the projector at one or two
+    images (19.3 -> 10.8 us each at one image), and plain single-segment Linear launches of a few hundred rows (the decoder's ref_point_head at one
+    image: 11.5 -> 6.9, 8.5 -> 6.4 us; at 1600 rows the 64 x 64 ring kernel ties or wins - profiles/r6c_*). LWDETR_GEMM_FEW=2 takes every plain
+    launch it can (tuning), =0 keeps lwdetr_gemm everywhere (A/B runs)."""
+    mode = os.environ.get("LWDETR_GEMM_FEW", "1")
+    if mode == "0" or dtype not in (torch.float16, torch.bfloat16) or M > GEMM_FEW_MAX_ROWS:
+        return False
+    if a_mode == A_CONV3x3:
+        return conv_cin in (128, 192)
+    return a_mode == A_PLAIN and K >= 256 and (mode == "2" or M <= 640)
+
+
+class GemmFewOp(GemmOp):
+    """GemmOp on lwdetr_gemm_few: ``W`` is pack_frag16 of the (N, K) matrix GemmOp takes; one LINEAR segment."""
+
+    def __init__(self, *a, **k):
+        k["splitk"] = 0
+        super().__init__(*a, **k)
+        self._fn = _nat.lib().lwdetr_gemm_few
 
 
 class AttnOp:

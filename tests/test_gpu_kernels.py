@@ -139,6 +139,46 @@ def test_gemm_conv3x3(dtype, stride, winmajor):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("b,hp,wp,cin,cout,stride", [(1, 40, 40, 128, 128, 1), (2, 40, 40, 128, 128, 1), (1, 40, 40, 192, 192, 1), (1, 25, 40, 128, 256, 1),
+                                                      (1, 40, 40, 128, 128, 2), (3, 24, 32, 192, 64, 2)])
+def test_gemm_few_rows_conv3x3_and_plain(dtype, b, hp, wp, cin, cout, stride):
+    """lwdetr_gemm_few (round 6: the few-row kernel - fragment-major weights straight from L2 into MFMA fragments, a third of the contraction per
+    L2 round trip, no LDS ring) vs F.conv2d / the fp32 product and vs lwdetr_gemm on the same operands: the projector's 3x3 convolutions at one and
+    two 640 x 640 images (40 x 40 pixels, 128 channels inside 640-wide rows), Cin = 192, a ragged last row tile (25 x 40 = 1000 = 62.5 tiles),
+    stride 2, more / fewer output columns than one workgroup's 128; and the PLAIN view with bias + GELU + LayerScale + residual + tap copy."""
+    from lwdetr_amd import kernels as K
+    ctot, col0 = cin + 96, 32
+    x = _rand(b, hp, wp, ctot, dtype=dtype, seed=1)
+    w = _rand(cout, cin, 3, 3, dtype=dtype, scale=(9 * cin) ** -0.5, seed=2)
+    bias = _rand(cout, seed=3)
+    ho, wo = (hp - 1) // stride + 1, (wp - 1) // stride + 1
+    m = b * ho * wo
+    wk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    assert K.gemm_few_supported(dtype, m, K.A_CONV3x3, cin)
+    outs = []
+    for cls, wt in ((K.GemmFewOp, K.pack_frag16(wk)), (K.GemmOp, wk)):
+        out = torch.full((m, cout + 8), 7.0, dtype=dtype, device=_dev())
+        cls(x.reshape(-1, ctot), wt, m, cout, 9 * cin, [K.seg(out, 0, cout, ldo=cout + 8, bias=bias, act=K.ACT_SILU)], lda=ctot, a_mode=K.A_CONV3x3,
+            a_tok=K.tok_layout(False, hp, wp, 0), conv_cin=cin, conv_stride=stride, a_col0=col0, conv_hout=ho, conv_wout=wo)()
+        outs.append(out)
+    xin = x[..., col0:col0 + cin].float().permute(0, 3, 1, 2)
+    ref = F.silu(F.conv2d(xin, w.float(), bias, stride=stride, padding=1)).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert _relerr(outs[0][:, :cout], ref) < TOL[dtype]
+    assert bool((outs[0][:, cout:] == 7.0).all())
+    assert _relerr(outs[0][:, :cout], outs[1][:, :cout].float()) < TOL[dtype] / 2
+    # PLAIN view, the full LINEAR epilogue
+    k, n = 9 * cin, cout
+    a = _rand(m, k, dtype=dtype, seed=4)
+    wl = _rand(n, k, dtype=dtype, scale=k ** -0.5, seed=5)
+    gamma, res = _rand(n, seed=6), _rand(m, n, dtype=dtype, seed=7)
+    o1, taps = torch.zeros(m, n, dtype=dtype, device=_dev()), torch.zeros(m, 2 * n, dtype=dtype, device=_dev())
+    K.GemmFewOp(a, K.pack_frag16(wl), m, n, k, [K.seg(o1, 0, n, ldo=n, bias=bias, act=K.ACT_GELU, scale=0.5, gamma=gamma, res=res, ldres=n,
+                                                   out2=taps[:, n:], ld2=2 * n)])()
+    refp = res.float() + gamma * 0.5 * F.gelu(a.float() @ wl.float().t() + bias)
+    assert _relerr(o1, refp) < TOL[dtype] and torch.equal(taps[:, n:], o1) and bool((taps[:, :n] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("stride,winmajor,cout", [(1, False, 192), (2, True, 384), (1, True, 128), (2, False, 256)])
 @pytest.mark.parametrize("wg2", ["0", "2"])
 def test_gemm_conv3x3_large_tile(dtype, stride, winmajor, cout, wg2, big_gemm, monkeypatch, knobs):
