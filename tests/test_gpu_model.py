@@ -420,7 +420,11 @@ def test_hip_graph_is_isolated_from_eager_calls_of_the_same_shape():
     assert (r2["pred_logits"] - p_logits).abs().max().item() > 1e-3                        # padding does change the result
 
 
-@pytest.mark.parametrize("size,batch,dtype", [("small", 32, torch.float16), ("medium", 64, torch.bfloat16), ("large", 32, torch.float16)])
+@pytest.mark.parametrize("size,batch,dtype", [("small", 32, torch.float16), ("medium", 64, torch.bfloat16), ("large", 32, torch.float16),
+                                              # round 6: the C = 768 model, 16 images per chain = 25 600 rows: QKV and fc1 of every block run on the
+                                              # persistent large-tile GEMM (gemm_pt.hip) in BOTH chains at once - its DMA ring, counted waits and
+                                              # register-direct epilogue beside another kernel's waves
+                                              ("xlarge", 32, torch.float16)])
 def test_two_launch_chains_equal_two_half_batches(size, batch, dtype):
     """Dense batches of >= 32 images run as two launch chains on two streams (LWDETR._forward_chains): the result is, bit for
     bit, what the model returns for the two half batches one after the other, and within 16-bit noise of the one-chain batch
@@ -436,7 +440,11 @@ def test_two_launch_chains_equal_two_half_batches(size, batch, dtype):
     try:
         L.set_streams(0)
         assert type(model)._chains_for(batch) == 2
+        from lwdetr_amd import _native
+        pt0 = _native.lib().lwdetr_gemm_pt_count()
         twos = [model(x) for _ in range(24)]          # repeated: kernels of the two chains share CUs in a different way every time
+        if size == "xlarge":
+            assert _native.lib().lwdetr_gemm_pt_count() - pt0 >= 24 * 2 * 2 * 10, "the persistent GEMM did not serve QKV / fc1 of both chains"
         two = twos[0]
         torch.cuda.synchronize()
         L.set_streams(1)
