@@ -38,7 +38,9 @@
 #endif
 #ifdef LWDETR_VB_TIMING
 __device__ unsigned long long g_vb_timing[2][4][16];
-#define VB_TS(i) do { if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) g_vb_timing[blockIdx.x != 0][wave][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// (slots 12 / 15: s_memtime = shader clocks at the first / last stamp - the clock the kernel actually ran at)
+#define VB_TS(i) do { if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) { g_vb_timing[blockIdx.x != 0][wave][i] = __builtin_amdgcn_s_memrealtime(); \
+    if ((i) == 0) g_vb_timing[blockIdx.x != 0][wave][12] = __builtin_amdgcn_s_memtime(); if ((i) == 11) g_vb_timing[blockIdx.x != 0][wave][15] = __builtin_amdgcn_s_memtime(); } } while (0)
 extern "C" int lwdetr_debug_vb_timing(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vb_timing), sizeof(g_vb_timing)) == hipSuccess ? 0 : 1;
 }
@@ -103,8 +105,18 @@ struct VbParams {
 
 #define VB_VMW(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // wait until at most n vector-memory operations of this wave are outstanding (n wave-uniform, rounded down to a multiple of 3)
+template <int N> __device__ __forceinline__ void vb_wait_const() {
+    static_assert(N >= 0 && N % 3 == 0 && N <= 24, "");
+    if constexpr (N == 0) VB_VMW(0); else if constexpr (N == 3) VB_VMW(3); else if constexpr (N == 6) VB_VMW(6); else if constexpr (N == 9) VB_VMW(9);
+    else if constexpr (N == 12) VB_VMW(12); else if constexpr (N == 15) VB_VMW(15); else if constexpr (N == 18) VB_VMW(18);
+    else if constexpr (N == 21) VB_VMW(21); else VB_VMW(24);
+}
+// STEADY: the count of the hidden loop's steady state ((NSLOT - 4) pieces x DPW in flight behind the step's two) - ONE compare in front of the
+// switch, which hipcc turns into a tree of ~15 scalar branches (round 6: the tree ran at every boundary of the 5-slot ring, whose steady
+// count was not the 12 tested here before)
+template <int STEADY>
 __device__ __forceinline__ void vb_wait_le(int n) {
-    if (n == 12) { VB_VMW(12); return; }            // the hidden loop's steady state (C = 192; 4 pieces x 3 in flight)
+    if (n == STEADY) { vb_wait_const<STEADY>(); return; }
     if (n >= 63) { VB_VMW(63); return; }
     switch (n / 3) {
         case 0: VB_VMW(0); break;   case 1: VB_VMW(3); break;   case 2: VB_VMW(6); break;   case 3: VB_VMW(9); break;
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
 #ifdef LWDETR_VB_TIMING
         const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
 #endif
-        vb_wait_le((issued - b) * DPW + extra);
+        vb_wait_le<(NSLOT - 4) * DPW>((issued - b) * DPW + extra);
 #ifdef LWDETR_VB_TIMING
         const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -524,6 +536,7 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<bool, true> Yes;
     typedef std::integral_constant<bool, false> No;
+    { constexpr int il = NTI - 2 + NSLOT; issued = il < NP ? il : NP; }      // (what it is after the projection's last boundary, as a constant)
     {   // pre-step: fc1(0)
         boundary(H0, H0 + 1, 0);
         const f32x16 bias = bias16(b1s);
@@ -552,6 +565,9 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
 #ifdef LWDETR_VB_TIMING
     if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && lane == 0) { g_vb_timing[blockIdx.x != 0][wave][13] = tt_wait; g_vb_timing[blockIdx.x != 0][wave][14] = tt_bar; }
 #endif
+    // the loop's last boundary was (H0 + 2 NCH - 4, ..): `issued` is a compile-time constant again from here on (hipcc does not see it through the
+    // run-time loop), and every later boundary - wait count, ring slots, pieces to issue - folds
+    { constexpr int il = H0 + 2 * NCH - 4 + NSLOT; issued = il < NP ? il : NP; }
     boundary(H0 + 2 * NCH - 2, H0 + 2 * NCH - 1, 0);
     iter(I1{}, Yes{}, No{}, H0 + 2 * NCH - 2, 0, NCH - 1);
     VB_TS(8);
@@ -640,19 +656,20 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
         const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc(p.k, 0, (int)p.qkv_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc(p.vt, 0, (int)p.qkv_bytes, 0x00020000);
         const int hd = 1 << p.hd_log2;
-        unsigned row_qk[NH];                      // element offset of this lane's token in q / k; 0x7fffffff = no token
+        // Store addresses: a per-lane byte offset computed ONCE (voffset; 0x80000000 = no token: out of the buffer's range) + a wave-uniform byte
+        // offset per group (soffset: SALU only) - no vector address arithmetic between the MFMAs. q / k (B, heads, Tp, hd): the lane's 8 features
+        // f = K + 8 h with K a multiple of 16 and hd >= 8, so column(f) = column(K) + column(8 h); v^T (B, heads, hd, Tp): row head * hd + d = f itself.
+        auto qk_col = [&](int f) -> unsigned { return (unsigned)((((long)(f >> p.hd_log2) * p.Tp) << p.hd_log2) + (f & (hd - 1))); };
+        unsigned vo_qk[NH];
 #pragma unroll
         for (int th = 0; th < NH; ++th) {
             const unsigned tok = (unsigned)t0 + 32 * th + j;
             const unsigned img = tok / (unsigned)p.Tp, wi = tok - img * (unsigned)p.Tp;
-            row_qk[th] = 32 * th + j < nvalid ? (unsigned)(((long)img * p.heads * p.Tp + wi) << p.hd_log2) : 0x7fffffffu;
+            vo_qk[th] = 32 * th + j < nvalid ? ((unsigned)(((long)img * p.heads * p.Tp + wi) << p.hd_log2) + qk_col(8 * h)) * 2u : 0x80000000u;
         }
-        // Vector-memory operations newer than the DMA of a step's pieces, for the counted wait (exact: every store below is
-        // issued unconditionally, invalid lanes store out of range): pieces are issued LAG steps ahead (earlier ones during
-        // the hidden loop, before the epilogue's stores).
         constexpr int XST = NH * NTI * 2, SPS = 2 * NH * 2, LAG = (NSLOT - 2) / 2;
         const int est = XST * (has_o2 ? 2 : 1);
-        unsigned row_v8[NH][2];                   // v^T: 8-token runs 32 th + 16 jb + 8 h .. of this lane
+        unsigned vo_v[NH][2];                     // v^T: 8-token runs 32 th + 16 jb + 8 h .. of this lane, feature row j
 #pragma unroll
         for (int th = 0; th < NH; ++th)
 #pragma unroll
@@ -660,78 +677,126 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
                 const int tl = 32 * th + 16 * jb + 8 * h;
                 const unsigned tk = (unsigned)t0 + tl;
                 const unsigned im = tk / (unsigned)p.Tp, wv = tk - im * (unsigned)p.Tp;
-                row_v8[th][jb] = tl < nvalid ? (unsigned)((long)im * p.heads * hd * p.Tp + wv) : 0x7fffffffu;
+                vo_v[th][jb] = tl < nvalid ? ((unsigned)((long)im * p.heads * hd * p.Tp + wv) + (unsigned)j * (unsigned)p.Tp) * 2u : 0x80000000u;
             }
-#pragma unroll 1
-        for (int s = 0; s < NP_QKV / 2; ++s) {
-            boundary(Q0 + 2 * s, Q0 + 2 * s + 2, s < LAG ? est + SPS * s : SPS * LAG);
+        // (pinned: computed HERE, once - left alone, hipcc sinks the divisions into the steps that first use the offsets and reloads their inputs
+        // from scratch there, and a scratch reload is a vmcnt(0) in the middle of the weight ring)
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int pi = 2 * s + pp, piece = Q0 + pi;
-                const int sg = pi / NTI, nl0 = (pi - sg * NTI) * 32;
-                f32x16 acc[NH];
-                if (sg < 2) {
-                    const f32x16 bias = bias16(bqs + sg * C + nl0);
-                    V8 fr[RD];
+        for (int th = 0; th < NH; ++th) asm volatile("" : "+v"(vo_qk[th]), "+v"(vo_v[th][0]), "+v"(vo_v[th][1]));
+        // A step = two pieces = 2 KS NH MFMAs. Round 6 (profiles/r6e_*): with the pieces one after the other - fragment round trip, KS dependent
+        // MFMAs, scale / conversion / half-wave exchange / addresses / stores - a step took 1.33 us for 0.37 us of matrix time (one wave per SIMD:
+        // nothing else fills the gaps), and the stores themselves cost nothing (ablated: the same). Now the step is software-pipelined like the
+        // hidden loop: the finished accumulators of step s - 1 (ping-pong) are turned into stores in GROUPS (8 accumulator registers -> one 16-byte
+        // store per lane) whose work is handed out in six LAYERS over the MFMA slots of step s - at most ~5 single-issue instructions fit
+        // beside a 32x32x16 MFMA of a wave that has its SIMD to itself, and an accumulator read or a transcendental counts double
+        // (tools/microbench/filler_bench.hip, profiles/r6e_*). The step's two pieces alternate (two independent accumulator chains) and start
+        // from zero: the bias is added in the group (f32, before the scale), not loaded into 32 accumulator registers per step.
+        constexpr int NS = NP_QKV / 2, NGR = 4 * NH, SLOTS = 2 * KS, GAP = SLOTS / NGR, NLAY = 6;
+        constexpr int RDQ = 4;                    // fragment read-ahead of this phase in MFMA slots
+        static_assert(NTI % 2 == 0 && SLOTS % NGR == 0 && GAP >= 3, "both pieces of a step belong to one of q / k / v");
+        f32x16 qacc[2][2][NH];                    // [ping-pong][piece of the step][token half]
+        float gv[8];                              // the group in flight: values, bias, packed pairs
+        f32x4 gb0, gb1;
+        float gbv = 0.f;
+        // (the step index is a compile-time constant throughout - q / k / v, ping-pong buffer and column offsets fold - NS steps of straight code)
+        auto layer = [&](auto sh_tag, auto g_tag, auto l_tag) {      // sh: the held step, g: its group, l: the layer
+            constexpr int sh = decltype(sh_tag)::value, BUF = sh & 1, g = decltype(g_tag)::value, L = decltype(l_tag)::value;
+            constexpr int pp = g / (2 * NH), jb = (g / NH) % 2, th = g % NH;
+            constexpr int pi = 2 * sh + pp, sg = pi / NTI, nl0 = (pi - sg * NTI) * 32;
+            // Instruction selection places what has no side effect wherever its operands allow - the conversions of a whole step ended up in
+            // front of its first MFMA, behind 24 hoisted fragment reads that no longer fitted the registers - and sched_barrier only binds the
+            // scheduler that runs after it. Every layer therefore BEGINS at an empty asm its inputs pass through (the accumulator tuple for the
+            // two reading layers) and ends at one its results pass through.
+            if constexpr (L <= 1) asm volatile("" : "+a"(qacc[BUF][pp][th]));
+            else asm volatile("" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]));
+            if constexpr (L == 0) {
 #pragma unroll
-                    for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
-#pragma unroll
-                    for (int t = 0; t < KS; ++t) {
-                        const V8 a = fr[t % RD];
-#pragma unroll
-                        for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(a, xf[th][t], t == 0 ? bias : acc[th]);
-                        if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (sg == 0) {                      // Q is pre-scaled (wave-uniform branch: K pieces skip the 16 NH multiplies)
-#pragma unroll
-                        for (int th = 0; th < NH; ++th)
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) acc[th][e] *= p.qscale;
-                    }
-#pragma unroll
-                    for (int jb = 0; jb < 2; ++jb) {
-                        const int f = nl0 + 16 * jb + 8 * h, hh = f >> p.hd_log2, dd = f & (hd - 1);      // 8 features of one head
-                        const unsigned col = (unsigned)(((long)hh * p.Tp << p.hd_log2) + dd);
-#pragma unroll
-                        for (int th = 0; th < NH; ++th) {
-                            const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
-                                                      pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
-                            const unsigned off = row_qk[th] == 0x7fffffffu ? 0x80000000u : (row_qk[th] + col) * 2u;
-                            if (sg == 0) __builtin_amdgcn_raw_buffer_store_b128(ow, r_q, off, 0, 0);
-                            else __builtin_amdgcn_raw_buffer_store_b128(ow, r_k, off, 0, 0);
-                        }
-                    }
+                for (int e = 0; e < 4; ++e) gv[e] = qacc[BUF][pp][th][8 * jb + e];
+                if constexpr (sg < 2) {           // rows 16 jb + 4 h + {0..3} and + 8 of the piece: features of D[feature][token]
+                    gb0 = *(const f32x4*)(bqs + sg * C + nl0 + 16 * jb + 4 * h);
+                    gb1 = *(const f32x4*)(bqs + sg * C + nl0 + 16 * jb + 8 + 4 * h);
                 } else {
-                    const float bv = bqs[2 * C + nl0 + j];
-                    f32x16 binit;
+                    // (the lane index from the hardware: the compiler keeps `j` in scratch here, and a scratch reload is a vmcnt(0) - it cannot
+                    // count the DMA it does not see - in the middle of the weight ring)
+                    unsigned ln;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                    gbv = bqs[2 * C + nl0 + (int)(ln & 31u)];      // D[token][feature]: one column per lane
+                }
+            } else if constexpr (L == 1) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) binit[e] = bv;
-                    V8 fr[RD];
+                for (int e = 0; e < 4; ++e) gv[4 + e] = qacc[BUF][pp][th][8 * jb + 4 + e];
+            } else if constexpr (L == 2) {
 #pragma unroll
-                    for (int i = 0; i < RD; ++i) fr[i] = frag(piece, i);
+                for (int e = 0; e < 4; ++e) gv[e] += sg < 2 ? gb0[e] : gbv;
+            } else if constexpr (L == 3) {
 #pragma unroll
-                    for (int t = 0; t < KS; ++t) {
-                        const V8 a = fr[t % RD];
+                for (int e = 0; e < 4; ++e) gv[4 + e] += sg < 2 ? gb1[e] : gbv;
+            } else if constexpr (L == 4) {
+                if constexpr (sg == 0) {            // Q is pre-scaled
 #pragma unroll
-                        for (int th = 0; th < NH; ++th) acc[th] = Mma32<T>::k16(xf[th][t], a, t == 0 ? binit : acc[th]);
-                        if (t + RD < KS) fr[t % RD] = frag(piece, t + RD);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    const int f = nl0 + j, hh = f >> p.hd_log2, dd = f & (hd - 1);
-                    const unsigned rowb = (unsigned)(((long)hh * hd + dd) * p.Tp);
-#pragma unroll
-                    for (int th = 0; th < NH; ++th)
-#pragma unroll
-                        for (int jb = 0; jb < 2; ++jb) {
-                            const u32x4 ow = vb_rows8(pack2<T>(acc[th][8 * jb], acc[th][8 * jb + 1]), pack2<T>(acc[th][8 * jb + 2], acc[th][8 * jb + 3]),
-                                                      pack2<T>(acc[th][8 * jb + 4], acc[th][8 * jb + 5]), pack2<T>(acc[th][8 * jb + 6], acc[th][8 * jb + 7]));
-                            const unsigned off = row_v8[th][jb] == 0x7fffffffu ? 0x80000000u : (row_v8[th][jb] + rowb) * 2u;
-                            __builtin_amdgcn_raw_buffer_store_b128(ow, r_v, off, 0, 0);
-                        }
+                    for (int e = 0; e < 8; ++e) gv[e] *= p.qscale;
+                }
+            } else {
+                const u32x4 ow = vb_rows8(pack2<T>(gv[0], gv[1]), pack2<T>(gv[2], gv[3]), pack2<T>(gv[4], gv[5]), pack2<T>(gv[6], gv[7]));
+                if constexpr (sg < 2) {
+                    const unsigned so = __builtin_amdgcn_readfirstlane(qk_col(nl0 + 16 * jb) * 2u);
+                    if constexpr (sg == 0) __builtin_amdgcn_raw_buffer_store_b128(ow, r_q, vo_qk[th], so, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(ow, r_k, vo_qk[th], so, 0);
+                } else {
+                    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)nl0 * (unsigned)p.Tp * 2u);
+                    __builtin_amdgcn_raw_buffer_store_b128(ow, r_v, vo_v[th][jb], so, 0);
                 }
             }
-        }
+            if constexpr (L < NLAY - 1)            // the layer stays in its slot
+                asm volatile("" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]));
+        };
+        vb_static_for<NS>([&](auto s_tag) {
+            constexpr int sidx = decltype(s_tag)::value, CUR = sidx & 1;
+            constexpr bool HELD = sidx > 0;
+            // vector-memory operations newer than the DMA of this step's last piece (issued at boundary s - LAG, or in the hidden loop) besides
+            // later pieces: the stores handed out during the steps s - LAG .. s - 1 = those of steps s - LAG - 1 .. s - 2, and the epilogue's when
+            // the piece went out before them (exact: every store is issued unconditionally, invalid lanes store out of range)
+            constexpr int fl = sidx - 1 < LAG ? (sidx - 1 > 0 ? sidx - 1 : 0) : LAG;
+            boundary(Q0 + 2 * sidx, Q0 + 2 * sidx + 2, (sidx < LAG ? est : 0) + SPS * fl);
+            constexpr int piece = Q0 + 2 * sidx, sg = (2 * sidx) / NTI;
+            auto fragq = [&](int i) -> V8 { return frag(piece + (i & 1), i >> 1); };      // slot i: piece i & 1, k-step i >> 1
+            V8 fr[RDQ];
+#pragma unroll
+            for (int i = 0; i < RDQ; ++i) fr[i] = fragq(i);
+            vb_static_for<SLOTS>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value, pp = i & 1, t = i >> 1;
+                // (the slot's MFMAs stay in the slot - between an empty asm their weight fragment passes through and one their result passes
+                // through: left to itself, instruction selection ran the twelve MFMAs of one accumulator back to back behind 24 hoisted reads)
+                asm volatile("" : "+v"(fr[i % RDQ]) :: "memory");
+                const V8 a = fr[i % RDQ];
+                // Q, K: D[feature][token]; V: operands swapped, D[token][feature]
+#pragma unroll
+                for (int th = 0; th < NH; ++th) {
+                    const f32x16 zero = {};
+#if LWDETR_VB_ABLATE & 2
+                    if constexpr (t == 0) qacc[CUR][pp][th] = zero;
+                    asm volatile("" : "+a"(qacc[CUR][pp][th]) : "v"(a), "v"(xf[th][t]));
+#else
+                    if constexpr (sg < 2) qacc[CUR][pp][th] = Mma32<T>::k16(a, xf[th][t], t == 0 ? zero : qacc[CUR][pp][th]);
+                    else qacc[CUR][pp][th] = Mma32<T>::k16(xf[th][t], a, t == 0 ? zero : qacc[CUR][pp][th]);
+                    asm volatile("" : "+a"(qacc[CUR][pp][th]));
+#endif
+                }
+#if !(LWDETR_VB_ABLATE & 8)
+                if constexpr (i + RDQ < SLOTS) fr[i % RDQ] = fragq(i + RDQ);
+#endif
+                if constexpr (HELD) {
+                    constexpr int g = i / GAP, o = i % GAP;
+                    vb_static_for<NLAY>([&](auto l_tag) {
+                        if constexpr (decltype(l_tag)::value * GAP / NLAY == o) layer(std::integral_constant<int, sidx - 1>{}, std::integral_constant<int, g>{}, l_tag);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        vb_static_for<NGR>([&](auto g_tag) {
+            vb_static_for<NLAY>([&](auto l_tag) { layer(std::integral_constant<int, NS - 1>{}, g_tag, l_tag); });
+        });
     }
     VB_TS(11);
 }
@@ -782,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_kernel(const VbParams p) {
     int issued = 0;
     auto boundary = [&](int a, int b, int extra) {
         __builtin_amdgcn_sched_barrier(0);
-        vb_wait_le((issued - b) * DPW + extra);
+        vb_wait_le<12>((issued - b) * DPW + extra);
         __builtin_amdgcn_s_barrier();
         int lim = a + NSLOT; lim = lim < NP ? lim : NP;
         while (issued < lim) { dma_piece(issued); ++issued; }
@@ -1021,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void vit_stem_kernel(const VsParams ps) {
     int issued = 0;
     auto boundary = [&](int a, int b, int extra) {
         __builtin_amdgcn_sched_barrier(0);
-        vb_wait_le((issued - b) * DPW + extra);
+        vb_wait_le<12>((issued - b) * DPW + extra);
         __builtin_amdgcn_s_barrier();
         int lim = a + NSLOT; lim = lim < NP ? lim : NP;
         while (issued < lim) { dma_piece(issued); ++issued; }

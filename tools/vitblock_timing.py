@@ -36,7 +36,8 @@ def main():
             t = [buf[(blk * 4 + w) * 16 + i] for i in range(16)]
             seg = [(t[i + 1] - t[i]) / 100.0 for i in range(11)]
             print(f"  wave {w}: " + "  ".join(f"{n} {s:.2f}" for n, s in zip(NAMES, seg)) +
-                  f"  | total {(t[11] - t[0]) / 100.0:.2f}  loop waits {t[13] / 100.0:.2f} barriers {t[14] / 100.0:.2f}")
+                  f"  | total {(t[11] - t[0]) / 100.0:.2f}  loop waits {t[13] / 100.0:.2f} barriers {t[14] / 100.0:.2f}"
+                  f"  shader clock {(t[15] - t[12]) / max(t[11] - t[0], 1) * 100.0:.0f} MHz")
 
 
 if __name__ == "__main__":
