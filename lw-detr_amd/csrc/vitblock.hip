@@ -249,6 +249,12 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
 #ifdef LWDETR_VB_TIMING
         const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
 #endif
+        // Every fragment read of the dead pieces has RETURNED before this wave signals: the barrier releases their ring slots to the DMA issued
+        // right behind it. The sched_barrier above does not guarantee that - instruction selection may still sink the MFMAs, and with them the
+        // lgkmcnt waits of their operands, below this point (round 6: a build in which 11 of the pre-step's 12 MFMAs sat behind the next
+        // boundary, their reads issued but not waited for, failed parity once in a few runs with two workgroups per CU). Free when
+        // nothing is outstanding, which is the designed state.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #ifdef LWDETR_VB_TIMING
         tt_wait += tb - ta; tt_bar += __builtin_amdgcn_s_memrealtime() - tb;
@@ -848,6 +854,7 @@ __global__ __launch_bounds__(256, 1) void vit_qkv_kernel(const VbParams p) {
     auto boundary = [&](int a, int b, int extra) {
         __builtin_amdgcn_sched_barrier(0);
         vb_wait_le<12>((issued - b) * DPW + extra);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (see vitblock_kernel's boundary)
         __builtin_amdgcn_s_barrier();
         int lim = a + NSLOT; lim = lim < NP ? lim : NP;
         while (issued < lim) { dma_piece(issued); ++issued; }
@@ -1087,6 +1094,7 @@ __global__ __launch_bounds__(256, 1) void vit_stem_kernel(const VsParams ps) {
     auto boundary = [&](int a, int b, int extra) {
         __builtin_amdgcn_sched_barrier(0);
         vb_wait_le<12>((issued - b) * DPW + extra);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (see vitblock_kernel's boundary)
         __builtin_amdgcn_s_barrier();
         int lim = a + NSLOT; lim = lim < NP ? lim : NP;
         while (issued < lim) { dma_piece(issued); ++issued; }
