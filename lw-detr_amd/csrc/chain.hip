@@ -150,8 +150,12 @@ struct WRing {
 #undef CH_C
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
-        // (no lgkmcnt wait: the fragment reads of the slots that are about to be freed have all been consumed by MFMAs in front of the
-        // sched_barrier above; the reads still in flight are the read-ahead into this tile's pieces)
+        // All LDS reads but the youngest CH_RD have returned: the reads still in flight are the read-ahead into THIS tile's pieces (issued last, and LDS
+        // reads return in order), everything older - the fragment reads of the slots that are about to be freed - is done before this wave signals.
+        // Until round 6 this relied on the MFMAs that consume those fragments sitting in front of the sched_barrier above; instruction selection
+        // does not promise that (vitblock.hip's boundary, profiles/r6e_*: a build that sank them below the barrier failed parity now and then).
+        // Free in the designed state.
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(CH_RD) : "memory");
 #ifdef LWDETR_CH_TIMING
         const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
 #endif
