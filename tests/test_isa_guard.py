@@ -101,3 +101,54 @@ def test_packed_f16_gelu_kernels_carry_only_straight_forms():
     # the kernels that existed before do not carry the packed-f16 forms (own instantiations: profiles/r5g_* is why)
     old = {k: v for k, v in funcs.items() if "vitblock_kernel" in k and k not in g16}
     assert len(old) == 12 and not any(re.match(r"v_(exp|rcp)_f16_sdwa\b", i) for v in old.values() for i in v)
+
+
+def _device_functions(obj):
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    dis = check_isa.device_disassembly(obj, "gfx950")
+    funcs, cur = {}, None
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", ln)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+        elif cur is not None and "//" in ln:
+            cur.append(ln.split("//")[0].strip())
+    return funcs
+
+
+def test_weight_ring_barriers_are_preceded_by_an_lds_read_drain():
+    """Round 6 (profiles/r6e_*): the barrier at a weight-ring boundary releases LDS slots to the DMA issued right behind it, so every fragment
+    read of those slots must have RETURNED when a wave signals. The source order (consuming MFMAs, then the boundary) does not guarantee that -
+    instruction selection may sink the MFMAs and their lgkmcnt waits below the barrier; one such build failed parity in 3 of 6 runs. The
+    kernels of vitblock.hip therefore carry `s_waitcnt lgkmcnt(0)` directly in front of every s_barrier, the exact-form ring of chain.hip
+    `s_waitcnt lgkmcnt(8)` (all but the read-ahead into the coming tile). Checked on the built objects."""
+    import re
+    base = os.path.join(ROOT, "lw-detr_amd", "csrc", "build")
+    if not os.path.exists(os.path.join(base, "vitblock.o")):
+        pytest.skip("library objects not built here")
+    funcs = _device_functions(os.path.join(base, "vitblock.o"))
+    ring = {k: v for k, v in funcs.items() if re.search(r"vitblock_kernel|vit_qkv_kernel|vit_stem_kernel", k)}
+    assert len(ring) >= 18 + 4, sorted(funcs)
+    for name, ins in ring.items():
+        bars = [i for i, x in enumerate(ins) if x == "s_barrier"]
+        assert len(bars) >= 2, (name, len(bars))      # (loops: a static barrier runs many times)
+        for b in bars:
+            # walking back from the barrier, the drain comes before any LDS read (arithmetic may sit in between: the compiler moves what has
+            # no side effect; ds_bpermute / ds_swizzle do not touch LDS memory)
+            j = b - 1
+            while j >= 0 and not re.search(r"^s_waitcnt .*lgkmcnt\(0\)|^s_waitcnt lgkmcnt\(0\)", ins[j]):
+                assert not re.match(r"ds_read|ds_load", ins[j]), (name, b, j, ins[j])
+                j -= 1
+            assert j >= 0, (name, b)
+    funcs = _device_functions(os.path.join(base, "chain.o"))
+    enc = {k: v for k, v in funcs.items() if "enc_chain_kernel" in k}
+    assert enc, sorted(funcs)
+    for name, ins in enc.items():
+        bars = [i for i, x in enumerate(ins) if x == "s_barrier"]
+        assert bars, name
+        for b in bars:
+            back = ins[max(0, b - 8):b]
+            m = [re.fullmatch(r"s_waitcnt (?:vmcnt\(\d+\) )?lgkmcnt\((\d+)\)", x) for x in back]
+            assert any(x and int(x.group(1)) <= 8 for x in m), (name, b, back)
