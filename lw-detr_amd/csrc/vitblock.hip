@@ -222,16 +222,20 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
         const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_dst);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(voff), "s"(sp) : "memory");
     };
-    auto dma_piece = [&](int piece) {
-        const unsigned slot = (unsigned)piece % NSLOT;
-        const char* src = wsrc + (size_t)piece * PIECE_B;
+    // the next piece to issue: its number, its source and its ring slot are carried along (no multiplication / modulo per piece in the run-time loop)
+    int issued = 0;
+    const char* isrc = wsrc;
+    unsigned ioff = 0;                          // byte offset of the slot of piece `issued`
+    auto dma_next = [&]() {
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
             const unsigned kb = (unsigned)(wave * DPW + i) * 1024u;
-            dma1k(src, kb + lane16, lds0 + slot * PIECE_B + kb);
+            dma1k(isrc, kb + lane16, lds0 + ioff + kb);
         }
+        ++issued; isrc += PIECE_B; ioff += PIECE_B;
+        if (ioff == NSLOT * PIECE_B) ioff = 0;
     };
-    int issued = 0;
+    auto issued_is = [&](int n) { issued = n; isrc = wsrc + (size_t)n * PIECE_B; ioff = (unsigned)(n % NSLOT) * PIECE_B; };      // (re-stated as constants)
     // step boundary: the step consumes pieces [a, b), everything below a is dead. `extra` = vector-memory operations this wave
     // is KNOWN to have issued after its DMA of piece b - 1 besides later pieces (a lower bound is safe, it only waits longer).
 #ifdef LWDETR_VB_TIMING
@@ -263,11 +267,13 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
 #if LWDETR_VB_ABLATE & 4
         if (a >= H0) { issued = lim; return; }
 #endif
-        while (issued < lim) { dma_piece(issued); ++issued; }
+        while (issued < lim) dma_next();
     };
     auto frag = [&](int piece, int f) -> V8 {
         return *(const V8*)(smem + ((unsigned)piece % NSLOT) * PIECE_B + f * 1024 + lane16);
     };
+    auto frag_o = [&](unsigned off, int f) -> V8 { return *(const V8*)(smem + off + f * 1024 + lane16); };      // by slot byte offset
+    auto next_off = [](unsigned off) { off += PIECE_B; return off == NSLOT * PIECE_B ? 0u : off; };
 
     VB_TS(0);
     // ---- prologue: vectors + the first NSLOT pieces in flight, then the attention rows as B fragments
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
             const unsigned kb = (unsigned)(wave * VEC_DPW + i) * 1024u;
             dma1k(vsrc, kb + lane16, lds0 + NSLOT * PIECE_B + kb);
         }
-        for (; issued < NSLOT; ++issued) dma_piece(issued);
+        while (issued < NSLOT) dma_next();
     }
     const T* att_w = (const T*)p.att + t0 * p.ldatt;
     T* x_w = (T*)p.x + t0 * p.ldx;
@@ -446,8 +452,8 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
         }
         return r;
     };
-    // one pipelined iteration. CUR: acc1 / hf buffer of chunk k; p2 / p1: pieces W2c(k-1) / W1c(k+1) (ignored when the half is off)
-    auto iter = [&](auto cur_tag, auto fc2_tag, auto fc1_tag, int p2, int p1, int k) {
+    // one pipelined iteration. CUR: acc1 / hf buffer of chunk k; o2 / o1: ring slots (byte offsets) of the pieces W2c(k-1) / W1c(k+1) (ignored when the half is off)
+    auto iter = [&](auto cur_tag, auto fc2_tag, auto fc1_tag, unsigned o2, unsigned o1, int k) {      // o2 / o1: slot offsets of the pieces W2c(k-1) / W1c(k+1)
         constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
         constexpr bool DO2 = decltype(fc2_tag)::value, DO1 = decltype(fc1_tag)::value;
         constexpr int NF2 = DO2 ? 2 * NTI : 0, NF1 = DO1 ? KS : 0, NF = NF2 + NF1, S = NF * NH;
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
         // wave per SIMD nothing else hides VALU / transcendental result latency (3-stage ticks on 2 values measured 1.8 us per
         // iteration). 8 layers x 2 NH groups of ticks over the iteration's MFMA slots.
         constexpr int NG = 2 * NH, NL = 8, TK = NL * NG;
-        auto fragi = [&](int i) -> V8 { return i < NF2 ? frag(p2, i) : frag(p1, i - NF2); };
+        auto fragi = [&](int i) -> V8 { return i < NF2 ? frag_o(o2, i) : frag_o(o1, i - NF2); };
         f32x16 bias = {};
         V8 fr[RD];
 #pragma unroll
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<bool, true> Yes;
     typedef std::integral_constant<bool, false> No;
-    { constexpr int il = NTI - 2 + NSLOT; issued = il < NP ? il : NP; }      // (what it is after the projection's last boundary, as a constant)
+    { constexpr int il = NTI - 2 + NSLOT; issued_is(il < NP ? il : NP); }      // (what it is after the projection's last boundary, as a constant)
     {   // pre-step: fc1(0)
         boundary(H0, H0 + 1, 0);
         const f32x16 bias = bias16(b1s);
@@ -555,17 +561,18 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
     }
     VB_TS(5);
     boundary(H0 + 1, H0 + 2, 0);
-    iter(I0{}, No{}, Yes{}, 0, H0 + 1, 0);
+    iter(I0{}, No{}, Yes{}, 0u, (unsigned)((H0 + 1) % NSLOT) * PIECE_B, 0);
     VB_TS(6);
 #ifdef LWDETR_VB_TIMING
     tt_wait = 0; tt_bar = 0;
 #endif
+    unsigned co = (unsigned)((H0 + 2) % NSLOT) * PIECE_B;      // slot of the next piece to consume (piece H0 + 2 k at the head of iteration k)
 #pragma unroll 1
     for (int k = 1; k < NCH - 1; k += 2) {
         boundary(H0 + 2 * k, H0 + 2 * k + 2, 0);
-        iter(I1{}, Yes{}, Yes{}, H0 + 2 * k, H0 + 2 * k + 1, k);
+        { const unsigned o1 = next_off(co); iter(I1{}, Yes{}, Yes{}, co, o1, k); co = next_off(o1); }
         boundary(H0 + 2 * k + 2, H0 + 2 * k + 4, 0);
-        iter(I0{}, Yes{}, Yes{}, H0 + 2 * k + 2, H0 + 2 * k + 3, k + 1);
+        { const unsigned o1 = next_off(co); iter(I0{}, Yes{}, Yes{}, co, o1, k + 1); co = next_off(o1); }
     }
     VB_TS(7);
 #ifdef LWDETR_VB_TIMING
@@ -573,9 +580,9 @@ __global__ __launch_bounds__(256, WPC) void vitblock_kernel(const VbParams p) {
 #endif
     // the loop's last boundary was (H0 + 2 NCH - 4, ..): `issued` is a compile-time constant again from here on (hipcc does not see it through the
     // run-time loop), and every later boundary - wait count, ring slots, pieces to issue - folds
-    { constexpr int il = H0 + 2 * NCH - 4 + NSLOT; issued = il < NP ? il : NP; }
+    { constexpr int il = H0 + 2 * NCH - 4 + NSLOT; issued_is(il < NP ? il : NP); }
     boundary(H0 + 2 * NCH - 2, H0 + 2 * NCH - 1, 0);
-    iter(I1{}, Yes{}, No{}, H0 + 2 * NCH - 2, 0, NCH - 1);
+    iter(I1{}, Yes{}, No{}, (unsigned)((H0 + 2 * NCH - 2) % NSLOT) * PIECE_B, 0u, NCH - 1);
     VB_TS(8);
     {   // post-step: fc2(NCH - 1)
         boundary(H0 + 2 * NCH - 1, H0 + 2 * NCH, 0);
