@@ -152,3 +152,35 @@ def test_weight_ring_barriers_are_preceded_by_an_lds_read_drain():
             back = ins[max(0, b - 8):b]
             m = [re.fullmatch(r"s_waitcnt (?:vmcnt\(\d+\) )?lgkmcnt\((\d+)\)", x) for x in back]
             assert any(x and int(x.group(1)) <= 8 for x in m), (name, b, back)
+
+
+def test_no_lds_read_is_outstanding_at_any_barrier_of_the_library():
+    """The same invariant over EVERY kernel of the product library, by counting: walking back from each s_barrier to the closest `s_waitcnt
+    ... lgkmcnt(N)` of its block, N plus the LDS reads issued in between = the reads that can still be in flight when the wave signals.
+    0 everywhere (a barrier in these kernels hands LDS data or LDS slots to somebody else), except the exact-form ring of the row-chain
+    kernels, whose read-ahead of 8 fragments into the coming tile is in flight by design (chain.hip: CH_RD)."""
+    import re
+    base = os.path.join(ROOT, "lw-detr_amd", "csrc", "build")
+    objs = sorted(glob.glob(os.path.join(base, "*.o")))
+    if not objs:
+        pytest.skip("library objects not built here")
+    seen = 0
+    for obj in objs:
+        for name, ins in _device_functions(obj).items():
+            for b in [i for i, x in enumerate(ins) if x == "s_barrier"]:
+                j, reads, n = b - 1, 0, None
+                while j >= 0:
+                    x = ins[j]
+                    m = re.search(r"lgkmcnt\((\d+)\)", x)
+                    if x.startswith("s_waitcnt") and m:
+                        n = int(m.group(1))
+                        break
+                    if re.match(r"ds_read|ds_load", x):
+                        reads += 1
+                    if x.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                        break                                  # top of the block: what came before is another path's business
+                    j -= 1
+                seen += 1
+                allowed = 8 if "enc_chain_kernel" in name else 0
+                assert reads + (n or 0) <= allowed, (os.path.basename(obj), name, b, reads, n)
+    assert seen > 500, seen
