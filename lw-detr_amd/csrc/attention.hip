@@ -658,9 +658,22 @@ int launch_lds(const lwdetr_attn_desc& p, hipStream_t st) {
 // this chip, tools/ubench/overlap.hip): 32 queries per wave keep the register count at 84-92 (5 waves per SIMD), which is
 // what hides the LDS / barrier latencies there; hd = 64 is matrix-bound and prefers the K / V^T reuse of 64 queries per wave.
 int g_attn_lds_cfg = 0;         // lwdetr_attention_tuning_cfg(): overrides the environment / default (tests)
+}  // namespace
+// The hd 16 instantiations of the ring kernel live in a second object built from THIS file with -DLWDETR_ATTN_HD16_TU -fno-slp-vectorize
+// (Makefile: attention_hd16.o): hipcc's SLP pass packs the softmax's f32 adds / multiplies into v_pk_*_f32, one of which costs what five plain
+// instructions cost beside an MFMA (tools/microbench/filler_bench.hip) - global attention at hd 16 is VALU-bound and loses 2 % to them
+// (profiles/r6f_*: 79.2 -> 77.6 us, config 2 +0.7 %), hd 64 is matrix-bound and WINS 0.9 % with the packed forms (xlarge), hd 32 does not care.
+extern "C" __attribute__((visibility("hidden"))) int lwdetr_attn_lds_hd16_impl(const lwdetr_attn_desc* p, int dtype, void* hip_stream, int cfg);
+namespace {
 template <typename T, int HD>
 int launch_lds_cfg(const lwdetr_attn_desc& p, hipStream_t st) {
     int c = g_attn_lds_cfg ? g_attn_lds_cfg : (int)lwdetr_knob(KNOB_ATTN_LDS_CFG, 0);
+#ifndef LWDETR_ATTN_HD16_TU
+    if constexpr (HD == 16) return lwdetr_attn_lds_hd16_impl(&p, std::is_same<T, f16>::value ? DT_F16 : DT_BF16, (void*)st, c);
+    else {
+#else
+    {
+#endif
     // a 100-key window = 4 waves of 32 queries. hd 16 (round 4): 128-query workgroups (13 per 1600-query image and head, the last
     // half idle; 4-5 resident per CU) beat 256-query ones (7, the last three quarters idle; 2 per CU): 161 vs 180 us on the bench
     // shape, +1.6 % on config 2 (profiles/r4f_attn_global_workgroup_sizes.txt); hd 32 is indifferent, hd 64 wants the K / V^T reuse
@@ -683,6 +696,7 @@ int launch_lds_cfg(const lwdetr_attn_desc& p, hipStream_t st) {
         case 3108: return launch_lds<T, HD, 1, 8, 4>(p, st);       // 256 keys per ring step
         case 1208: return launch_lds<T, HD, 2, 8, 2>(p, st);
         default: return LWDETR_ERR_UNSUPPORTED;
+    }
     }
 }
 template <typename T, int HD> struct LdsPath {
@@ -1155,6 +1169,13 @@ int dispatch_hd(const lwdetr_attn_desc& p, hipStream_t st) {
 
 }  // namespace
 
+#ifdef LWDETR_ATTN_HD16_TU
+// (this object: the hd 16 ring kernels only; `cfg` = the tuning override of the main object, 0 = none)
+extern "C" __attribute__((visibility("hidden"))) int lwdetr_attn_lds_hd16_impl(const lwdetr_attn_desc* p, int dtype, void* hip_stream, int cfg) {
+    g_attn_lds_cfg = cfg;
+    return dtype == DT_F16 ? launch_lds_cfg<f16, 16>(*p, (hipStream_t)hip_stream) : launch_lds_cfg<bf16, 16>(*p, (hipStream_t)hip_stream);
+}
+#else
 extern "C" void lwdetr_attention_tuning(int lds_mode) { g_attn_lds_mode = lds_mode; }
 extern "C" void lwdetr_attention_tuning_cfg(int cfg) { g_attn_lds_cfg = cfg; }
 
@@ -1175,3 +1196,4 @@ extern "C" int lwdetr_attention(const lwdetr_attn_desc* desc, int dtype, void* h
         default: return LWDETR_ERR_UNSUPPORTED;
     }
 }
+#endif  // LWDETR_ATTN_HD16_TU
