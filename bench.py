@@ -318,8 +318,24 @@ def log(msg):
 # ---- GPU telemetry beside the timed region (round 6): the boxes of this pool differ by 12-15 % on the same tree and the record
 # carried no clock, power or temperature to tell a slow draw from a slow tree. Read from the card's sysfs hwmon files (no subprocess, nothing on the GPU - but milliseconds per sample:
 # never between the warm-up and the timed region); `rocm-smi --json` once as the fallback. All failures are swallowed: telemetry never costs the line.
+_HWMON_DIR = []          # [path or None, how it was chosen] once resolved
+
+
 def _hwmon_dir():
+    """hwmon directory of THE card this process computes on: the drm card whose PCI address is device 0's (a multi-GPU host shows every card in
+    sysfs whatever the container may use - round 6's first version read the first AMD card it found, which on those hosts is somebody else's:
+    95 MHz and 243 W 'under load'); the first AMD card only when the address cannot be matched (recorded in `card`)."""
     import glob
+    if _HWMON_DIR:
+        return _HWMON_DIR[0]
+    want = None
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        want = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:      # noqa: BLE001
+        pass
+    first = None
     for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
         try:
             if open(os.path.join(card, "vendor")).read().strip() != "0x1002":
@@ -327,9 +343,15 @@ def _hwmon_dir():
         except OSError:
             continue
         hw = sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*")))
-        if hw:
+        if not hw:
+            continue
+        addr = os.path.basename(os.path.realpath(card))
+        if want and addr.startswith(want):
+            _HWMON_DIR[:] = [hw[0], "pci address %s of device 0" % addr]
             return hw[0]
-    return None
+        first = first or (hw[0], "first AMD card in sysfs (%s; device 0 is %s)" % (addr, want))
+    _HWMON_DIR[:] = list(first) if first else [None, "none"]
+    return _HWMON_DIR[0]
 
 
 _HWMON = {"sclk_mhz": ("freq1_input", 1e-6), "mclk_mhz": ("freq2_input", 1e-6), "power_w": ("power1_average", 1e-6), "power_input_w": ("power1_input", 1e-6),
@@ -348,6 +370,8 @@ def gpu_telemetry(hw=None):
                 pass
     if out:
         out["source"] = "sysfs hwmon"
+        if _HWMON_DIR:
+            out["card"] = _HWMON_DIR[1]
         return out
     try:
         import subprocess
