@@ -1,5 +1,9 @@
 """Phase timing of lwdetr_vit_block (tuning tool, not part of the product).
 
+NOTE (end of round 6): since vitblock.o is built without SLP vectorisation the INSTRUMENTED kernel spills far more than the product kernel (192 against 24
+bytes of scratch per lane; its LayerNorm phase reads 8.6 us instead of ~3.5) - the stamps no longer describe the product kernel's phases one to one
+(profiles/r6g_*). The ablation builds compare like with like and remain usable.
+
 Build the instrumented library first (on the build host):   python tools/vitblock_timing.py --build
 Run on the GPU:  LWDETR_HIP_LIB=tools/_timing/liblwdetr_hip_vbt.so python tools/vitblock_timing.py [C batch dtype]"""
 import ctypes as C
